@@ -1,0 +1,110 @@
+"""
+ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/nvae_oracle.py header for the rules).
+
+CPU restatement of the classifier, the defender wrapper and EoT on the purification path:
+  src/classifier/model.py:31-49               Vgg (torchvision vgg11_bn + projector head)
+  src/defenses/ours/abstract_models.py:53-62  BaseClassificationModel.__call__
+  src/defenses/ours/abstract_models.py:129-193 MLVGMDefenseModel (noise, blur, purify, classify)
+  src/defenses/wrappers.py:15-24              EoTWrapper.forward
+
+Third-party arithmetic restated here (absent from the reference tree and from this image, versions unpinned in
+environment.yml:10,17): torchvision `vgg11_bn` topology; kornia `normalize` ((x-mean)/std per channel) and
+`filters.gaussian_blur2d(x, k, (1,1))` (separable, 'reflect' border, kernel = normalised exp(-(i-(k-1)/2)^2/2)).
+These third-party pieces are parity-unpinned by any reference fixture; the golden vectors pin everything
+that lives in the reference tree itself.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from gen_adversarial_amd.vgg_spec import VggSpec
+from gen_adversarial_amd.nvae_spec import NVAESpec
+from oracle.nvae_oracle import nvae_purify
+
+SD = Dict[str, torch.Tensor]
+
+
+def vgg_forward(sd: SD, spec: VggSpec, x: torch.Tensor) -> torch.Tensor:
+    """Vgg.forward — src/classifier/model.py:47-49 (torchvision VGG.forward: features, avgpool(7,7), flatten, classifier)."""
+    for op in spec.program:
+        if op[0] == 'pool':
+            x = F.max_pool2d(x, 2, 2)
+        else:
+            _, i, _, _ = op
+            x = F.conv2d(x, sd[f'model.features.{i}.weight'], sd[f'model.features.{i}.bias'], padding=1)
+            b = f'model.features.{i + 1}'
+            x = F.batch_norm(x, sd[f'{b}.running_mean'], sd[f'{b}.running_var'], sd[f'{b}.weight'], sd[f'{b}.bias'],
+                             False, 0.0, 1e-5)
+            x = F.relu(x)
+    x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
+    x = F.linear(x, sd['model.classifier.0.weight'])
+    c = 'model.classifier.1'
+    x = F.batch_norm(x, sd[f'{c}.running_mean'], sd[f'{c}.running_var'], sd[f'{c}.weight'], sd[f'{c}.bias'],
+                     False, 0.0, 1e-5)
+    x = F.relu(x)
+    return F.linear(x, sd['model.classifier.3.weight'], sd['model.classifier.3.bias'])
+
+
+def classifier_call(sd: SD, spec: VggSpec, batch: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """BaseClassificationModel.__call__ — abstract_models.py:53-62 with the CelebaIdentityClassifier
+    constants (models.py:45-47)."""
+    m = torch.tensor(mean).view(1, 3, 1, 1)
+    s = torch.tensor(std).view(1, 3, 1, 1)
+    return vgg_forward(sd, spec, (batch - m) / s)
+
+
+def add_gaussian_noise(x: torch.Tensor, noise: torch.Tensor, eps: float) -> torch.Tensor:
+    """MLVGMDefenseModel.add_gaussian_noise — abstract_models.py:129-143, with the N(0,1) draw passed in."""
+    norm = torch.norm(noise.view(noise.size(0), -1), dim=1, keepdim=True)
+    scaled = noise * (eps / norm.view(-1, 1, 1, 1))
+    return (x + scaled).clamp(0.0, 1.0)
+
+
+def gaussian_kernel1d(k: int, sigma: float = 1.0) -> torch.Tensor:
+    xs = torch.arange(k, dtype=torch.float32) - (k - 1) / 2.0 if k % 2 == 1 else torch.arange(k, dtype=torch.float32) - k // 2 + 0.5
+    g = torch.exp(-xs.pow(2) / (2 * sigma * sigma))
+    return g / g.sum()
+
+
+def blur_kernel_size(h: int) -> int:
+    """abstract_models.py:150-156: k = int(2**(sqrt(h)//2) - 1)."""
+    return int(2 ** (math.sqrt(h) // 2) - 1)
+
+
+def apply_gaussian_blur(x: torch.Tensor) -> torch.Tensor:
+    """MLVGMDefenseModel.apply_gaussian_blur — abstract_models.py:145-159 (kornia gaussian_blur2d, sigma (1,1),
+    default border_type='reflect', separable)."""
+    b, c, h, w = x.shape
+    k = blur_kernel_size(h)
+    g = gaussian_kernel1d(k).to(x)
+    p = k // 2
+    y = F.pad(x, (p, p, p, p), mode='reflect')
+    y = F.conv2d(y, g.view(1, 1, 1, k).expand(c, 1, 1, k), groups=c)
+    y = F.conv2d(y, g.view(1, 1, k, 1).expand(c, 1, k, 1), groups=c)
+    return y
+
+
+def nvae_defender(nvae_sd: SD, nvae_spec: NVAESpec, vgg_sd: SD, vgg_spec: VggSpec, batch: torch.Tensor,
+                  alphas: Sequence[float], eps: List[torch.Tensor], input_noise: torch.Tensor,
+                  noise_eps: float = 0.0, blur: bool = False, temperature: float = 0.6):
+    """MLVGMDefenseModel.__call__ for NVAEDefenseModel (mean/std None => no extra normalisation) —
+    abstract_models.py:161-193.  Returns (logits, purified)."""
+    if blur:
+        batch = apply_gaussian_blur(batch)
+    batch = add_gaussian_noise(batch, input_noise, noise_eps)
+    purified = nvae_purify(nvae_sd, nvae_spec, batch, alphas, eps, temperature)
+    logits = classifier_call(vgg_sd, vgg_spec, purified)
+    return logits, purified
+
+
+def eot_defender(nvae_sd, nvae_spec, vgg_sd, vgg_spec, image: torch.Tensor, eot_steps: int, alphas, eps,
+                 input_noise, noise_eps=0.0, blur=False, temperature=0.6):
+    """EoTWrapper.forward — wrappers.py:15-24: repeat the single image eot_steps times, mean logits over rows."""
+    x = image.repeat(eot_steps, 1, 1, 1)
+    logits, purified = nvae_defender(nvae_sd, nvae_spec, vgg_sd, vgg_spec, x, alphas, eps, input_noise,
+                                     noise_eps, blur, temperature)
+    return torch.mean(logits, dim=0, keepdim=True), purified

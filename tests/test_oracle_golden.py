@@ -1,0 +1,120 @@
+"""
+CPU: the oracle (our restatement) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Tolerance 1e-5 as stated in BASELINE.md §3.
+"""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, load_golden
+from gen_adversarial_amd.nvae_spec import (DecCellSpec, EncCellSpec, _Rng, _dec_cell, _enc_cell, build_spec,
+                                           init_nvae_state_dict)
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
+from oracle import defender_oracle as D
+from oracle import nvae_oracle as O
+
+CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive']
+TOL = 1e-5
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _setup(g):
+    cfg, res = golden_cfg(g)
+    spec = build_spec(cfg, res)
+    sd = init_nvae_state_dict(cfg, res, int(g['nvae_seed']))
+    vspec = build_vgg_spec(int(g['n_classes']), int(g['width_div']))
+    vsd = init_vgg_state_dict(int(g['n_classes']), int(g['width_div']), int(g['vgg_seed']))
+    alphas = [float(a) * float(g['attenuation']) for a in g['alphas']]
+    return spec, sd, vspec, vsd, alphas
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_state_dict_layout_matches_reference(name, golden_cases):
+    g = golden_cases[name]
+    cfg, res = golden_cfg(g)
+    sd = init_nvae_state_dict(cfg, res, 0)
+    ref = {str(k): ast.literal_eval(str(s)) for k, s in zip(g['sd_keys'], g['sd_shapes'])}
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in sd.items():
+        assert tuple(v.shape) == ref[k], k
+    vsd = init_vgg_state_dict(int(g['n_classes']), int(g['width_div']), 0)
+    vref = {str(k): ast.literal_eval(str(s)) for k, s in zip(g['vgg_keys'], g['vgg_shapes'])}
+    assert set(vsd.keys()) == set(vref.keys())
+    for k, v in vsd.items():
+        assert tuple(v.shape) == vref[k], k
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_purify_matches_reference(name, golden_cases):
+    g = golden_cases[name]
+    spec, sd, _, _, alphas = _setup(g)
+    eps = [_t(g[f'eps_{i}']) for i in range(len(spec.groups))]
+    out = O.nvae_purify(sd, spec, _t(g['x']), alphas, eps, 0.6)
+    np.testing.assert_allclose(out.numpy(), g['purified_only'], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_defender_logits_and_input_grad(name, golden_cases):
+    g = golden_cases[name]
+    spec, sd, vspec, vsd, alphas = _setup(g)
+    eps = [_t(g[f'eps_{i}']) for i in range(len(spec.groups))]
+    x = _t(g['x']).clone().requires_grad_(True)
+    logits, purified = D.nvae_defender(sd, spec, vsd, vspec, x, alphas, eps, _t(g['input_noise']),
+                                       float(g['noise_eps']))
+    np.testing.assert_allclose(purified.detach().numpy(), g['purified'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(logits.detach().numpy(), g['logits'], atol=TOL, rtol=0)
+    (gx,) = torch.autograd.grad((logits * _t(g['cotangent'])).sum(), [x])
+    np.testing.assert_allclose(gx.numpy(), g['grad_x'], atol=TOL, rtol=0)
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_eot_wrapper_and_ce_grad(name, golden_cases):
+    g = golden_cases[name]
+    spec, sd, vspec, vsd, alphas = _setup(g)
+    eot = int(g['eot_steps'])
+    eps = [_t(g[f'eot_eps_{i}']) for i in range(len(spec.groups))]
+    x1 = _t(g['x'][:1]).clone().requires_grad_(True)
+    logits, _ = D.eot_defender(sd, spec, vsd, vspec, x1, eot, alphas, eps, _t(g['eot_noise']), float(g['noise_eps']))
+    np.testing.assert_allclose(logits.detach().numpy(), g['eot_logits'], atol=TOL, rtol=0)
+    loss = torch.nn.functional.cross_entropy(logits, logits.argmax(dim=1))
+    (gx,) = torch.autograd.grad(loss, [x1])
+    np.testing.assert_allclose(gx.numpy(), g['eot_ce_grad'], atol=TOL, rtol=0)
+
+
+def test_cells_match_reference_modules():
+    g = load_golden('nvae_modules.npz')
+    cases = [('enc_same', EncCellSpec('c', 8, 8, False)), ('enc_down', EncCellSpec('c', 8, 16, True)),
+             ('dec_same', DecCellSpec('c', 8, 8, False, 6)), ('dec_up', DecCellSpec('c', 8, 4, True, 3))]
+    for name, cell in cases:
+        sd = {}
+        rng = _Rng(int(g[f'{name}_seed']))
+        if isinstance(cell, EncCellSpec):
+            _enc_cell(sd, rng, cell)
+            fn = O.enc_cell
+        else:
+            _dec_cell(sd, rng, cell)
+            fn = O.dec_cell
+        x = _t(g[f'{name}_x']).clone().requires_grad_(True)
+        y = fn(sd, cell, x)
+        np.testing.assert_allclose(y.detach().numpy(), g[f'{name}_y'], atol=TOL, rtol=0, err_msg=name)
+        (gx,) = torch.autograd.grad((y * _t(g[f'{name}_cot'])).sum(), [x])
+        np.testing.assert_allclose(gx.numpy(), g[f'{name}_gx'], atol=TOL, rtol=0, err_msg=name)
+
+
+def test_dml_mean_and_normal():
+    g = load_golden('nvae_modules.npz')
+    lg = _t(g['dml_logits']).clone().requires_grad_(True)
+    y = O.disc_mix_logistic_mean(lg, 10)
+    np.testing.assert_allclose(y.detach().numpy(), g['dml_mean'], atol=TOL, rtol=0)
+    (gl,) = torch.autograd.grad((y * _t(g['dml_cot'])).sum(), [lg])
+    np.testing.assert_allclose(gl.numpy(), g['dml_glogits'], atol=TOL, rtol=0)
+    mu, sigma = O.normal_mu_sigma(_t(g['normal_mu_in']), _t(g['normal_ls_in']), 0.6)
+    np.testing.assert_allclose(mu.numpy(), g['normal_mu'], atol=TOL, rtol=0)
+    np.testing.assert_allclose(sigma.numpy(), g['normal_sigma'], atol=1e-5, rtol=1e-6)
+    z = mu + _t(g['normal_eps']) * sigma
+    np.testing.assert_allclose(z.numpy(), g['normal_z'], atol=1e-5, rtol=1e-6)
