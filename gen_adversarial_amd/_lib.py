@@ -1,0 +1,209 @@
+"""
+ctypes binding of libga_ops.so (include/ga_ops.h).  The product path has NO fallback: if the library is missing or
+fails to load, importing this module raises.
+
+Structures mirror include/ga_ops.h field for field; tests/test_abi.py checks sizeof(ga_op) against the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libga_ops.so')
+
+GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU = 0, 1, 2, 3
+(GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
+ GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY) = range(1, 12)
+ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
+
+fp = C.c_void_p     # device pointers travel as integers
+i32 = C.c_int
+f32 = C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', fp), ('ldx', i32), ('x2', fp), ('ldx2', i32), ('w', fp), ('bias', fp),
+                ('pro_scale', fp), ('pro_shift', fp), ('addend', fp), ('ldadd', i32),
+                ('addend2', fp), ('ldadd2', i32), ('dact_x', fp), ('lddact', i32),
+                ('dact_scale', fp), ('dact_shift', fp), ('y', fp), ('ldy', i32),
+                ('N', i32), ('Hi', i32), ('Wi', i32), ('C1', i32), ('C2', i32),
+                ('Ho', i32), ('Wo', i32), ('Cout', i32),
+                ('KH', i32), ('KW', i32), ('sn', i32), ('sd', i32), ('pad', i32),
+                ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32)]
+
+
+class DwDesc(C.Structure):
+    _fields_ = [('x', fp), ('w', fp), ('bias', fp), ('dact_x', fp), ('y', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32),
+                ('pro_act', i32), ('dact_act', i32), ('up2', i32), ('pool2', i32)]
+
+
+class ReduceDesc(C.Structure):
+    _fields_ = [('a', fp), ('b', fp), ('out', fp), ('N', i32), ('P', i32), ('C', i32), ('scale', f32)]
+
+
+class SeExciteDesc(C.Structure):
+    _fields_ = [('m', fp), ('w1', fp), ('b1', fp), ('w2', fp), ('b2', fp), ('hid', fp), ('gate', fp),
+                ('dgate', fp), ('pro_scale', fp), ('pro_shift', fp),
+                ('N', i32), ('C', i32), ('Hd', i32), ('P', i32), ('res_scale', f32), ('backward', i32)]
+
+
+class SeApplyDesc(C.Structure):
+    _fields_ = [('skip', fp), ('t', fp), ('gate', fp), ('out', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('skip_mode', i32), ('res_scale', f32)]
+
+
+class BilinearBwdDesc(C.Structure):
+    _fields_ = [('dhigh', fp), ('dlow', fp), ('N', i32), ('h', i32), ('w', i32), ('C', i32), ('accumulate', i32)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [('mu_q', fp), ('ldq', i32), ('p', fp), ('ldp', i32), ('eps', fp), ('eps_nchw', i32),
+                ('z', fp), ('dz', fp), ('dmu_q', fp), ('dp', fp),
+                ('N', i32), ('h', i32), ('w', i32), ('NL', i32),
+                ('alpha', f32), ('one_minus_alpha', f32), ('temp', f32), ('backward', i32)]
+
+
+class DmlDesc(C.Structure):
+    _fields_ = [('logits', fp), ('ld', i32), ('nmix', i32), ('img_nchw', fp), ('img_nhwc', fp),
+                ('dimg_nhwc', fp), ('dimg_nchw', fp), ('dlogits', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('backward', i32)]
+
+
+class MaxpoolDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('dy', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32),
+                ('backward', i32)]
+
+
+class ImageIoDesc(C.Structure):
+    _fields_ = [('x_nchw', fp), ('noise_nchw', fp), ('noise_coef', fp), ('y_nhwc', fp), ('dy_nhwc', fp),
+                ('dx_nchw', fp), ('N', i32), ('C', i32), ('H', i32), ('W', i32), ('rep', i32), ('backward', i32)]
+
+
+class AxpbyDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('n', C.c_long), ('alpha', f32), ('beta', f32)]
+
+
+class _OpUnion(C.Union):
+    _fields_ = [('conv', ConvDesc), ('dw', DwDesc), ('red', ReduceDesc), ('se', SeExciteDesc), ('app', SeApplyDesc),
+                ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
+                ('io', ImageIoDesc), ('ax', AxpbyDesc)]
+
+
+class Op(C.Structure):
+    _fields_ = [('kind', i32), ('_pad', i32), ('u', _OpUnion)]
+
+
+_KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_OP_SE_EXCITE: 'se',
+               GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
+               GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax'}
+_DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
+              SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
+              DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY}
+
+EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
+           'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
+           'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                          f'or `make -C gen_adversarial_amd/csrc` — there is no CPU fallback on the product path')
+    lib = C.CDLL(LIB_PATH)
+    for n, d in (('ga_conv2d', ConvDesc), ('ga_dwconv5', DwDesc), ('ga_rowchan_reduce', ReduceDesc),
+                 ('ga_se_excite', SeExciteDesc), ('ga_se_apply', SeApplyDesc), ('ga_bilinear_up2_bwd', BilinearBwdDesc),
+                 ('ga_sampler_mix', SamplerDesc), ('ga_dml_mean', DmlDesc), ('ga_maxpool2', MaxpoolDesc),
+                 ('ga_image_io', ImageIoDesc)):
+        f = getattr(lib, n)
+        f.argtypes = [C.POINTER(d), C.c_void_p]
+        f.restype = C.c_int
+    lib.ga_axpby.argtypes = [fp, fp, C.c_long, f32, f32, C.c_void_p]
+    lib.ga_axpby.restype = C.c_int
+    lib.ga_plan_run.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+    lib.ga_plan_run.restype = C.c_int
+    lib.ga_plan_time.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.c_int, C.POINTER(f32), C.POINTER(f32),
+                                 C.POINTER(C.c_long)]
+    lib.ga_plan_time.restype = C.c_int
+    lib.ga_last_hip_error.restype = C.c_char_p
+    lib.ga_abi_version.restype = C.c_int
+    lib.ga_sizeof_op.restype = C.c_ulong
+    if lib.ga_sizeof_op() != C.sizeof(Op):
+        raise ImportError(f'ABI mismatch: library ga_op is {lib.ga_sizeof_op()} bytes, binding is {C.sizeof(Op)}')
+    return lib
+
+
+lib = _load()
+
+
+class GaError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        extra = f' ({lib.ga_last_hip_error().decode()})' if rc == -4 else ''
+        raise GaError(f'{what}: {ERRORS.get(rc, rc)}{extra}')
+
+
+def make_op(desc) -> Op:
+    op = Op()
+    op.kind = _DESC_KIND[type(desc)]
+    setattr(op.u, _KIND_FIELD[op.kind], desc)
+    return op
+
+
+_DIRECT = {ConvDesc: 'ga_conv2d', DwDesc: 'ga_dwconv5', ReduceDesc: 'ga_rowchan_reduce', SeExciteDesc: 'ga_se_excite',
+           SeApplyDesc: 'ga_se_apply', BilinearBwdDesc: 'ga_bilinear_up2_bwd', SamplerDesc: 'ga_sampler_mix',
+           DmlDesc: 'ga_dml_mean', MaxpoolDesc: 'ga_maxpool2', ImageIoDesc: 'ga_image_io'}
+
+
+def run(desc, stream: int = 0):
+    """Launch one op directly through its own C entry point."""
+    if isinstance(desc, AxpbyDesc):
+        check(lib.ga_axpby(desc.x, desc.y, desc.n, desc.alpha, desc.beta, stream), 'ga_axpby')
+        return
+    name = _DIRECT[type(desc)]
+    check(getattr(lib, name)(C.byref(desc), stream), name)
+
+
+class Plan:
+    """A flat list of ops replayed by one ga_plan_run call."""
+
+    def __init__(self):
+        self.descs = []
+        self.names = []
+        self._arr = None
+
+    def add(self, desc, name: str = ''):
+        self.descs.append(desc)
+        self.names.append(name)
+        self._arr = None
+
+    def finalize(self):
+        arr = (Op * len(self.descs))()
+        for i, d in enumerate(self.descs):
+            arr[i] = make_op(d)
+        self._arr = arr
+        return self
+
+    def __len__(self):
+        return len(self.descs)
+
+    def run(self, stream: int = 0):
+        if self._arr is None:
+            self.finalize()
+        failed = C.c_int(-1)
+        rc = lib.ga_plan_run(self._arr, len(self.descs), stream, C.byref(failed))
+        if rc != 0:
+            check(rc, f'plan op #{failed.value} ({self.names[failed.value]})')
+
+    def time(self, stream: int = 0, iters: int = 1, per_conv: bool = False):
+        if self._arr is None:
+            self.finalize()
+        total, conv, nconv = f32(0), f32(0), C.c_long(0)
+        rc = lib.ga_plan_time(self._arr, len(self.descs), stream, iters, C.byref(total),
+                              C.byref(conv) if per_conv else None, C.byref(nconv) if per_conv else None)
+        check(rc, 'ga_plan_time')
+        return total.value, conv.value, nconv.value

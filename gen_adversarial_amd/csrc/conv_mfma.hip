@@ -1,0 +1,281 @@
+// ga_conv2d — fp32 implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// GEMM view: C[M = N*Ho*Wo pixels][Cout] = A[M][K = taps*(C1+C2)] * B[K][Cout].
+//   * A is gathered on the fly from the NHWC activation (im2col never materialised); the prologue
+//     (per-channel / per-(row,channel) affine + SiLU/ELU/ReLU) is applied in registers between the global load
+//     and the LDS write, so activations are stored once, pre-activation, and re-used by the backward pass.
+//   * B (weights) is stored [Cout][K] so that both operands are "row x contiguous-k" in LDS.
+//   * LDS rows are BK=32 floats + 4 pad (144 B): a ds_read_b128 of 4 consecutive k for 16 different rows hits 16
+//     distinct 16-B slots (9*i mod 16 is a bijection) -> conflict-free for every ds_read_b128 lane group.
+//   * One ds_read_b128 per operand feeds FOUR MFMAs: within an 8-wide k block, lane half h (= lane>>5) owns
+//     k = 4h..4h+3 and MFMA step s uses k = 4h+s for A and B alike (the order of the fma chain inside K is free).
+//   * 256 threads = 4 waves arranged WM x WN, each wave owns TM x TN tiles of 32x32; accumulators stay in registers
+//     for the whole K loop; global->register prefetch of tile t+1 overlaps the MFMAs of tile t (double-buffered
+//     LDS, one barrier per K tile).
+//   * Output channel sits on the lane (C/D layout: col = lane&31), so each accumulator register row is a 128-B
+//     contiguous NHWC store; bias / act' / addend are applied in the epilogue.
+//   * blockIdx is remapped so that consecutive logical tiles (which share the A panel) run on one XCD's L2.
+#include "ga_common.h"
+
+namespace ga {
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+
+template <int WM, int WN, int TM, int TN, bool VEC>
+__global__ void __launch_bounds__(256)
+conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDK;
+
+    // ---- XCD-aware tile order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch); give each XCD a
+    //      contiguous range of logical tiles.  Bijective for any grid size.
+    int bid;
+    {
+        const int nb = gridDim.x, orig = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = orig & 7, k = orig >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int c4 = tid & 7, r0 = tid >> 3;
+
+    const int HoWo = d.Ho * d.Wo;
+    int a_n[RA], a_h0[RA], a_w0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < M) {
+            const int n = m / HoWo, rem = m - n * HoWo, ho = rem / d.Wo, wo = rem - ho * d.Wo;
+            a_n[i] = n; a_h0[i] = ho * d.sn - d.pad; a_w0[i] = wo * d.sn - d.pad;
+        } else { a_n[i] = -1; a_h0[i] = 0; a_w0[i] = 0; }
+    }
+
+    floatx4 ra[RA], rb[RB];
+
+    auto load_tile = [&](const int t) {
+        const int tap = t / nkc, c0 = (t - tap * nkc) * BK;
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        const int c = c0 + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_n[i] >= 0 && c < Ctot) {
+                int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                bool ok = (hi >= 0) & (wi >= 0);
+                if (d.sd != 1) { ok = ok && (hi % d.sd == 0) && (wi % d.sd == 0); hi /= d.sd; wi /= d.sd; }
+                ok = ok && hi < d.Hi && wi < d.Wi;
+                if (ok) {
+                    const size_t pix = ((size_t)a_n[i] * d.Hi + hi) * d.Wi + wi;
+                    if (VEC) {
+                        if (c < d.C1) {
+                            v = *reinterpret_cast<const floatx4*>(d.x + pix * d.ldx + c);
+                            if (d.pro_scale) {
+                                const size_t po = (d.pro_per_row ? (size_t)a_n[i] * d.C1 : 0) + c;
+                                const floatx4 s = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
+                                const floatx4 b = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
+                                v = v * s + b;
+                            }
+                            if (d.pro_act) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], d.pro_act);
+                            }
+                        } else {
+                            v = *reinterpret_cast<const floatx4*>(d.x2 + pix * d.ldx2 + (c - d.C1));
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int ce = c + e;
+                            if (ce < d.C1) {
+                                float u = d.x[pix * d.ldx + ce];
+                                if (d.pro_scale) {
+                                    const size_t po = (d.pro_per_row ? (size_t)a_n[i] * d.C1 : 0) + ce;
+                                    u = u * d.pro_scale[po] + d.pro_shift[po];
+                                }
+                                v[e] = act_fwd(u, d.pro_act);
+                            } else if (ce < Ctot) {
+                                v[e] = d.x2[pix * d.ldx2 + (ce - d.C1)];
+                            }
+                        }
+                    }
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            floatx4 v = {0.f, 0.f, 0.f, 0.f};
+            const int co = n0 + r0 + 32 * i;
+            if (co < d.Cout && c < Ctot) {
+                const float* wp = d.w + (size_t)co * Ktot + (size_t)tap * Ctot + c;
+                if (VEC) {
+                    v = *reinterpret_cast<const floatx4*>(wp);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c + e < Ctot) v[e] = wp[e];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+
+    auto store_tile = [&](const int buf) {
+        float* Ab = As + buf * BM * LDK;
+        float* Bb = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<floatx4*>(Ab + (r0 + 32 * i) * LDK + 4 * c4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<floatx4*>(Bb + (r0 + 32 * i) * LDK + 4 * c4) = rb[i];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int T = d.KH * d.KW * nkc;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < T) load_tile(t + 1);
+        const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + 4 * lh;
+        const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            floatx4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const floatx4*>(Ab + i * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const floatx4*>(Bb + j * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < T) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = n0 + wn * TN * 32 + j * 32 + lrow;
+        if (co >= d.Cout) continue;
+        const float bias = d.bias ? d.bias[co] : 0.f;
+        float ds = 1.f, db = 0.f;
+        if (d.dact_x && d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bias;
+                if (d.dact_x) {
+                    const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
+                    v *= act_bwd(u, d.dact_act) * ds;
+                }
+                if (d.addend) {
+                    const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+                    v += d.addend[am * d.ldadd + co];
+                }
+                if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
+                d.y[(size_t)m * d.ldy + co] = v;
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int M = d.N * d.Ho * d.Wo;
+    const int Ctot = d.C1 + d.C2;
+    const int Ktot = d.KH * d.KW * Ctot;
+    const int nkc = (Ctot + BK - 1) / BK;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
+    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    const dim3 grid(tilesM * tilesN), block(256);
+    if (vec) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, true>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, false>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc);
+    }
+    return check_launch();
+}
+
+}  // namespace ga
+
+extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
+    using namespace ga;
+    if (!dp) return GA_E_BADARG;
+    const ga_conv_desc& d = *dp;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (!d.x || !d.w || !d.y) return GA_E_BADARG;
+    if (d.N <= 0 || d.Hi <= 0 || d.Wi <= 0 || d.C1 <= 0 || d.C2 < 0 || d.Ho <= 0 || d.Wo <= 0 || d.Cout <= 0) return GA_E_BADARG;
+    if (d.KH <= 0 || d.KW <= 0 || d.sn <= 0 || d.sd <= 0 || d.pad < 0) return GA_E_BADARG;
+    if (d.C2 > 0 && !d.x2) return GA_E_BADARG;
+    if ((d.pro_scale == nullptr) != (d.pro_shift == nullptr)) return GA_E_BADARG;
+    if (d.dact_x && ((d.dact_scale == nullptr) != (d.dact_shift == nullptr))) return GA_E_BADARG;
+    if (d.ldx < d.C1 || (d.C2 > 0 && d.ldx2 < d.C2) || d.ldy < d.Cout) return GA_E_BADARG;
+    if (d.addend && d.ldadd < d.Cout) return GA_E_BADARG;
+    if (d.addend2 && d.ldadd2 < d.Cout) return GA_E_BADARG;
+    if (d.dact_x && d.lddact < d.Cout) return GA_E_BADARG;
+    // every output pixel must map inside the gather formula's domain (host-side shape check, no device faults)
+    if ((long)d.N * d.Ho * d.Wo > 0x7fffffffL) return GA_E_UNSUPPORTED;
+    if ((long)d.KH * d.KW * (d.C1 + d.C2) > 0x7fffffffL) return GA_E_UNSUPPORTED;
+
+    const bool vec = (d.C1 % 4 == 0) && (d.C2 % 4 == 0) && (d.ldx % 4 == 0) && (d.C2 == 0 || d.ldx2 % 4 == 0) &&
+                     aligned16(d.x) && aligned16(d.w) && (d.C2 == 0 || aligned16(d.x2)) &&
+                     (!d.pro_scale || (aligned16(d.pro_scale) && aligned16(d.pro_shift)));
+
+    int tile = d.tile;
+    if (tile == 0) {
+        const long M = (long)d.N * d.Ho * d.Wo;
+        if (d.Cout <= 32) tile = 4;
+        else if (d.Cout <= 64) tile = (M >= 128 * 256) ? 2 : 3;
+        else {
+            const long b128 = ((M + 127) / 128) * ((d.Cout + 127) / 128);
+            const long b12864 = ((M + 127) / 128) * ((d.Cout + 63) / 64);
+            if (b128 >= 512) tile = 1;
+            else if (b12864 >= 512) tile = 2;
+            else tile = 3;
+        }
+    }
+    switch (tile) {
+        case 1: return launch_conv<2, 2, 2, 2>(d, stream, vec);
+        case 2: return launch_conv<4, 1, 1, 2>(d, stream, vec);
+        case 3: return launch_conv<2, 2, 1, 1>(d, stream, vec);
+        case 4: return launch_conv<4, 1, 1, 1>(d, stream, vec);
+        default: return GA_E_UNSUPPORTED;
+    }
+}

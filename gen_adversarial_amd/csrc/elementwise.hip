@@ -1,0 +1,431 @@
+// HBM-bound element-wise / reduction kernels of the purification path (NHWC, float4 = 16 B per lane where the
+// channel count allows).  Each kernel cites the reference code whose arithmetic it restates.
+#include "ga_common.h"
+
+namespace ga {
+
+// ---------------------------------------------------------------------------------------------------------------
+// out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)
+// SE squeeze = torch.mean(x, dim=[2,3]) (NVAE/modules/architecture.py:56) and its backward partner d(gate).
+// block = 16 channel-quads x 16 pixel lanes; fixed summation order => bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_reduce_desc d, const int nchunks) {
+    __shared__ floatx4 part[16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, pl = tid >> 4;
+    const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    const int c = chunk * 64 + 4 * c4;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < d.C) {
+        const float* a = d.a + (size_t)n * d.P * d.C + c;
+        const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
+        for (int p = pl; p < d.P; p += 16) {
+            floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+            if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+            acc += v;
+        }
+    }
+    part[pl][c4] = acc;
+    __syncthreads();
+    if (pl == 0 && c < d.C) {
+        floatx4 s = part[0][c4];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) s += part[i][c4];
+        *reinterpret_cast<floatx4*>(d.out + (size_t)n * d.C + c) = s * d.scale;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SE excite: relu(linear_1) -> sigmoid(linear_2) (architecture.py:57-58) and its backward.  One block per row.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc d) {
+    extern __shared__ float sm[];
+    float* s_in = sm;            // C
+    float* s_hid = sm + d.C;     // Hd
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!d.backward) {
+        for (int c = tid; c < d.C; c += 256) s_in[c] = d.m[(size_t)n * d.C + c];
+        __syncthreads();
+        for (int j = wave; j < d.Hd; j += 4) {
+            float acc = 0.f;
+            for (int c = lane; c < d.C; c += 64) acc += d.w1[(size_t)j * d.C + c] * s_in[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) { const float h = acc + d.b1[j]; s_hid[j] = h; d.hid[(size_t)n * d.Hd + j] = h; }
+        }
+        __syncthreads();
+        for (int c = tid; c < d.C; c += 256) {
+            float acc = d.b2[c];
+            for (int j = 0; j < d.Hd; ++j) acc += d.w2[(size_t)c * d.Hd + j] * fmaxf(s_hid[j], 0.f);
+            d.gate[(size_t)n * d.C + c] = sigmoidf_(acc);
+        }
+    } else {
+        // ds[c] = dgate * gate * (1 - gate)
+        for (int c = tid; c < d.C; c += 256) {
+            const float g = d.gate[(size_t)n * d.C + c];
+            s_in[c] = d.dgate[(size_t)n * d.C + c] * g * (1.f - g);
+        }
+        __syncthreads();
+        for (int j = wave; j < d.Hd; j += 4) {
+            float acc = 0.f;
+            for (int c = lane; c < d.C; c += 64) acc += d.w2[(size_t)c * d.Hd + j] * s_in[c];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) s_hid[j] = d.hid[(size_t)n * d.Hd + j] > 0.f ? acc : 0.f;
+        }
+        __syncthreads();
+        const float invP = 1.0f / (float)d.P;
+        for (int c = tid; c < d.C; c += 256) {
+            float acc = 0.f;
+            for (int j = 0; j < d.Hd; ++j) acc += d.w1[(size_t)j * d.C + c] * s_hid[j];
+            d.pro_scale[(size_t)n * d.C + c] = d.res_scale * d.gate[(size_t)n * d.C + c];
+            d.pro_shift[(size_t)n * d.C + c] = acc * invP;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bilinear x2, align_corners=True (F.interpolate in SkipUp, architecture.py:92): source index and lambda
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_src(const int o, const int in, const int out, int& i0, int& i1, float& l1) {
+    const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float src = scale * (float)o;
+    i0 = (int)src;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// out = skip + res_scale * gate[n,c] * t   (ResidualCell*.forward: `x + 0.1 * residual`, architecture.py:133-136,183-186,
+// with the SE channel scale x * se (:61) folded in)
+__global__ void __launch_bounds__(256) se_apply_kernel(const ga_se_apply_desc d, const long total4) {
+    const int C4 = d.C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4); long p = i / C4;
+        const int w = (int)(p % d.W); p /= d.W;
+        const int h = (int)(p % d.H); const int n = (int)(p / d.H);
+        const int c = 4 * c4;
+        const floatx4 t = *reinterpret_cast<const floatx4*>(d.t + i * 4);
+        const floatx4 g = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
+        floatx4 s;
+        if (d.skip_mode == 0) {
+            s = *reinterpret_cast<const floatx4*>(d.skip + i * 4);
+        } else {
+            const int hl = d.H / 2, wl = d.W / 2;
+            int h0, h1, w0, w1; float lh, lw;
+            bil_src(h, hl, d.H, h0, h1, lh);
+            bil_src(w, wl, d.W, w0, w1, lw);
+            const float* base = d.skip + (size_t)n * hl * wl * d.C + c;
+            const floatx4 x00 = *reinterpret_cast<const floatx4*>(base + ((size_t)h0 * wl + w0) * d.C);
+            const floatx4 x01 = *reinterpret_cast<const floatx4*>(base + ((size_t)h0 * wl + w1) * d.C);
+            const floatx4 x10 = *reinterpret_cast<const floatx4*>(base + ((size_t)h1 * wl + w0) * d.C);
+            const floatx4 x11 = *reinterpret_cast<const floatx4*>(base + ((size_t)h1 * wl + w1) * d.C);
+            const float h0l = 1.f - lh, w0l = 1.f - lw;
+            s = h0l * (w0l * x00 + lw * x01) + lh * (w0l * x10 + lw * x11);
+        }
+        *reinterpret_cast<floatx4*>(d.out + i * 4) = s + d.res_scale * g * t;
+    }
+}
+
+// adjoint of the bilinear x2 read above (gather form, deterministic)
+__global__ void __launch_bounds__(256) bilinear_up2_bwd_kernel(const ga_bilinear_up2_bwd_desc d, const long total4) {
+    const int C4 = d.C / 4;
+    const int H = 2 * d.h, W = 2 * d.w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4); long p = i / C4;
+        const int wl = (int)(p % d.w); p /= d.w;
+        const int hl = (int)(p % d.h); const int n = (int)(p / d.h);
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* base = d.dhigh + (size_t)n * H * W * d.C + 4 * c4;
+        // candidate high-res rows/cols: src = o*(in-1)/(out-1) in (l-1, l+1)
+        const int hlo = max(0, 2 * hl - 2), hhi = min(H - 1, 2 * hl + 4);
+        const int wlo = max(0, 2 * wl - 2), whi = min(W - 1, 2 * wl + 4);
+        for (int hh = hlo; hh <= hhi; ++hh) {
+            int h0, h1; float lh;
+            bil_src(hh, d.h, H, h0, h1, lh);
+            const float wh = (h0 == hl ? 1.f - lh : 0.f) + (h1 == hl ? lh : 0.f);
+            if (wh == 0.f) continue;
+            for (int ww = wlo; ww <= whi; ++ww) {
+                int w0, w1; float lw;
+                bil_src(ww, d.w, W, w0, w1, lw);
+                const float wwt = (w0 == wl ? 1.f - lw : 0.f) + (w1 == wl ? lw : 0.f);
+                if (wwt == 0.f) continue;
+                acc += (wh * wwt) * *reinterpret_cast<const floatx4*>(base + ((size_t)hh * W + ww) * d.C);
+            }
+        }
+        floatx4* o = reinterpret_cast<floatx4*>(d.dlow + i * 4);
+        *o = d.accumulate ? (*o + acc) : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// latent interpolation (src/defenses/ours/models.py:199-206,246-250; distributions.py:20-48)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softclamp5(float x) { return tanhf(x / 5.0f) * 5.0f; }
+__device__ __forceinline__ float dsoftclamp5(float x) { const float t = tanhf(x / 5.0f); return 1.0f - t * t; }
+
+__global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, const long total) {
+    const int hw = d.h * d.w;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % d.NL); const long pix = i / d.NL;            // pix = n*hw + p
+        const int n = (int)(pix / hw), p = (int)(pix % hw);
+        const float mq = d.mu_q[pix * d.ldq + c];
+        const float mp = d.p ? d.p[pix * d.ldp + c] : 0.f;
+        const float ls = d.p ? d.p[pix * d.ldp + d.NL + c] : 0.f;
+        const float e = d.eps_nchw ? d.eps[((size_t)n * d.NL + c) * hw + p] : d.eps[i];
+        const float sig = d.temp * expf(softclamp5(ls));
+        const float a = d.alpha, om = d.one_minus_alpha;
+        if (!d.backward) {
+            const float enc_mu = softclamp5(mp + mq);
+            const float smp = e * sig + softclamp5(mp);
+            d.z[i] = om * enc_mu + a * smp;
+        } else {
+            const float dz = d.dz[i];
+            const float denc = om * dz * dsoftclamp5(mp + mq);
+            d.dmu_q[pix * d.ldq + c] = denc;
+            if (d.dp) {
+                d.dp[pix * d.ldp + c] = denc + a * dz * dsoftclamp5(mp);
+                d.dp[pix * d.ldp + d.NL + c] = a * dz * e * sig * dsoftclamp5(ls);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DiscMixLogistic.mean + denormalise (distributions.py:103-129,231-254; models.py:271-274); one thread per pixel
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DML_MAXMIX = 16;
+
+__global__ void __launch_bounds__(256) dml_kernel(const ga_dml_desc d, const long npix) {
+    const int HW = d.H * d.W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const float* l = d.logits + i * d.ld;
+        const int nm = d.nmix;
+        float p[DML_MAXMIX];
+        float mx = -INFINITY;
+        for (int k = 0; k < nm; ++k) mx = fmaxf(mx, l[k]);
+        float den = 0.f;
+        for (int k = 0; k < nm; ++k) { p[k] = expf(l[k] - mx); den += p[k]; }
+        const float inv = 1.0f / den;
+        float mu0 = 0.f, mu1 = 0.f, mu2 = 0.f, K0 = 0.f, K1 = 0.f, K2 = 0.f;
+        for (int k = 0; k < nm; ++k) {
+            p[k] *= inv;
+            const float* q = l + nm + 9 * k;
+            mu0 += q[0] * p[k]; mu1 += q[1] * p[k]; mu2 += q[2] * p[k];
+            K0 += tanhf(q[6]) * p[k]; K1 += tanhf(q[7]) * p[k]; K2 += tanhf(q[8]) * p[k];
+        }
+        const float r = fminf(fmaxf(mu0, -1.f), 1.f);
+        const float gpre = mu1 + K0 * r;
+        const float g = fminf(fmaxf(gpre, -1.f), 1.f);
+        const float bpre = mu2 + K1 * r + K2 * g;
+        const float bl = fminf(fmaxf(bpre, -1.f), 1.f);
+        const int n = (int)(i / HW), pp = (int)(i % HW);
+        if (!d.backward) {
+            const float o0 = r * 0.5f + 0.5f, o1 = g * 0.5f + 0.5f, o2 = bl * 0.5f + 0.5f;
+            if (d.img_nhwc) { float* o = d.img_nhwc + i * 3; o[0] = o0; o[1] = o1; o[2] = o2; }
+            if (d.img_nchw) {
+                float* o = d.img_nchw + (size_t)n * 3 * HW + pp;
+                o[0] = o0; o[HW] = o1; o[2 * HW] = o2;
+            }
+        } else {
+            float dr = 0.f, dg = 0.f, db = 0.f;
+            if (d.dimg_nhwc) { const float* q = d.dimg_nhwc + i * 3; dr += q[0]; dg += q[1]; db += q[2]; }
+            if (d.dimg_nchw) { const float* q = d.dimg_nchw + (size_t)n * 3 * HW + pp; dr += q[0]; dg += q[HW]; db += q[2 * HW]; }
+            dr *= 0.5f; dg *= 0.5f; db *= 0.5f;
+            const float dbp = (bpre >= -1.f && bpre <= 1.f) ? db : 0.f;
+            const float dmu2 = dbp, dK1 = dbp * r, dK2 = dbp * g;
+            dr += dbp * K1; dg += dbp * K2;
+            const float dgp = (gpre >= -1.f && gpre <= 1.f) ? dg : 0.f;
+            const float dmu1 = dgp, dK0 = dgp * r;
+            dr += dgp * K0;
+            const float dmu0 = (mu0 >= -1.f && mu0 <= 1.f) ? dr : 0.f;
+            float* o = d.dlogits + i * d.ld;
+            float dpk[DML_MAXMIX];
+            float dot = 0.f;
+            for (int k = 0; k < nm; ++k) {
+                const float* q = l + nm + 9 * k;
+                const float t0 = tanhf(q[6]), t1 = tanhf(q[7]), t2 = tanhf(q[8]);
+                dpk[k] = q[0] * dmu0 + q[1] * dmu1 + q[2] * dmu2 + t0 * dK0 + t1 * dK1 + t2 * dK2;
+                dot += p[k] * dpk[k];
+                float* oq = o + nm + 9 * k;
+                oq[0] = p[k] * dmu0; oq[1] = p[k] * dmu1; oq[2] = p[k] * dmu2;
+                oq[3] = 0.f; oq[4] = 0.f; oq[5] = 0.f;
+                oq[6] = p[k] * dK0 * (1.f - t0 * t0); oq[7] = p[k] * dK1 * (1.f - t1 * t1); oq[8] = p[k] * dK2 * (1.f - t2 * t2);
+            }
+            for (int k = 0; k < nm; ++k) o[k] = p[k] * (dpk[k] - dot);
+            for (int k = nm + 9 * nm; k < d.ld; ++k) o[k] = 0.f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2x2/2 max pool (torchvision VGG 'M'), on pre-activation maps
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool2_kernel(const ga_maxpool2_desc d, const long total4) {
+    const int C4 = d.C / 4, Ho = d.H / 2, Wo = d.W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c4 = (int)(i % C4); long p = i / C4;
+        const int wo = (int)(p % Wo); p /= Wo;
+        const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+        const size_t base = (((size_t)n * d.H + 2 * ho) * d.W + 2 * wo) * d.C + 4 * c4;
+        const floatx4 a = *reinterpret_cast<const floatx4*>(d.x + base);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(d.x + base + d.C);
+        const floatx4 c = *reinterpret_cast<const floatx4*>(d.x + base + (size_t)d.W * d.C);
+        const floatx4 e = *reinterpret_cast<const floatx4*>(d.x + base + (size_t)d.W * d.C + d.C);
+        if (!d.backward) {
+            floatx4 m;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], e[k]));
+            *reinterpret_cast<floatx4*>(d.y + i * 4) = m;
+        } else {
+            const floatx4 g = *reinterpret_cast<const floatx4*>(d.dy + i * 4);
+            floatx4 ga_ = {0.f, 0.f, 0.f, 0.f}, gb = ga_, gc = ga_, ge = ga_;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // first maximal element in scan order (a, b, c, e), as aten::max_pool2d_with_indices keeps it
+                float m = a[k]; int w = 0;
+                if (b[k] > m) { m = b[k]; w = 1; }
+                if (c[k] > m) { m = c[k]; w = 2; }
+                if (e[k] > m) { m = e[k]; w = 3; }
+                if (w == 0) ga_[k] = g[k]; else if (w == 1) gb[k] = g[k]; else if (w == 2) gc[k] = g[k]; else ge[k] = g[k];
+            }
+            *reinterpret_cast<floatx4*>(d.dx + base) = ga_;
+            *reinterpret_cast<floatx4*>(d.dx + base + d.C) = gb;
+            *reinterpret_cast<floatx4*>(d.dx + base + (size_t)d.W * d.C) = gc;
+            *reinterpret_cast<floatx4*>(d.dx + base + (size_t)d.W * d.C + d.C) = ge;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// image boundary: NCHW <-> NHWC, EoT repeat, input noise + clamp (abstract_models.py:129-143; wrappers.py:20)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d, const long total) {
+    const int HW = d.H * d.W;
+    if (!d.backward) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            // i indexes NCHW of the N rows (coalesced reads), writes NHWC
+            const int p = (int)(i % HW); long q = i / HW;
+            const int c = (int)(q % d.C); const int n = (int)(q / d.C);
+            float v = d.x_nchw[((size_t)(n / d.rep) * d.C + c) * HW + p];
+            if (d.noise_nchw) v += d.noise_nchw[i] * d.noise_coef[n];
+            d.y_nhwc[((size_t)n * HW + p) * d.C + c] = fminf(fmaxf(v, 0.f), 1.f);
+        }
+    } else {
+        const long total_img = total / d.rep;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_img; i += (long)gridDim.x * 256) {
+            const int p = (int)(i % HW); long q = i / HW;
+            const int c = (int)(q % d.C); const int img = (int)(q / d.C);
+            const float x = d.x_nchw[i];
+            float acc = 0.f;
+            for (int r = 0; r < d.rep; ++r) {
+                const int n = img * d.rep + r;
+                float v = x;
+                if (d.noise_nchw) v += d.noise_nchw[((size_t)n * d.C + c) * HW + p] * d.noise_coef[n];
+                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[((size_t)n * HW + p) * d.C + c];
+            }
+            d.dx_nchw[i] = acc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) axpby_kernel(const float* x, float* y, const long n, const float a, const float b) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+static inline unsigned grid_for(long items) {
+    long b = (items + 255) / 256;
+    if (b > 2048 * 4) b = 2048 * 4;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace ga
+
+using namespace ga;
+
+extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
+    if (!d || !d->a || !d->out || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!aligned16(d->a) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
+    const int nchunks = (d->C + 63) / 64;
+    hipLaunchKernelGGL(rowchan_reduce_kernel, dim3(d->N * nchunks), dim3(256), 0, (hipStream_t)s, *d, nchunks);
+    return check_launch();
+}
+
+extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
+    if (!d || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->hid || !d->gate || d->N <= 0 || d->C <= 0 || d->Hd <= 0) return GA_E_BADARG;
+    if (!d->backward && !d->m) return GA_E_BADARG;
+    if (d->backward && (!d->dgate || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
+    const size_t lds = (size_t)(d->C + d->Hd) * sizeof(float);
+    if (lds > 64 * 1024) return GA_E_UNSUPPORTED;
+    hipLaunchKernelGGL(se_excite_kernel, dim3(d->N), dim3(256), lds, (hipStream_t)s, *d);
+    return check_launch();
+}
+
+extern "C" int ga_se_apply(const ga_se_apply_desc* d, void* s) {
+    if (!d || !d->skip || !d->t || !d->gate || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (d->skip_mode == 1 && ((d->H | d->W) & 1)) return GA_E_BADARG;
+    if (d->skip_mode != 0 && d->skip_mode != 1) return GA_E_UNSUPPORTED;
+    if (!aligned16(d->skip) || !aligned16(d->t) || !aligned16(d->gate) || !aligned16(d->out)) return GA_E_ALIGN;
+    const long total4 = (long)d->N * d->H * d->W * (d->C / 4);
+    hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_bilinear_up2_bwd(const ga_bilinear_up2_bwd_desc* d, void* s) {
+    if (!d || !d->dhigh || !d->dlow || d->N <= 0 || d->h <= 0 || d->w <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!aligned16(d->dhigh) || !aligned16(d->dlow)) return GA_E_ALIGN;
+    const long total4 = (long)d->N * d->h * d->w * (d->C / 4);
+    hipLaunchKernelGGL(bilinear_up2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
+    if (!d || !d->mu_q || !d->eps || d->N <= 0 || d->h <= 0 || d->w <= 0 || d->NL <= 0) return GA_E_BADARG;
+    if (d->ldq < d->NL || (d->p && d->ldp < 2 * d->NL)) return GA_E_BADARG;
+    if (!d->backward && !d->z) return GA_E_BADARG;
+    if (d->backward && (!d->dz || !d->dmu_q || (d->p && !d->dp))) return GA_E_BADARG;
+    const long total = (long)d->N * d->h * d->w * d->NL;
+    hipLaunchKernelGGL(sampler_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
+    return check_launch();
+}
+
+extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
+    if (!d || !d->logits || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->nmix <= 0) return GA_E_BADARG;
+    if (d->nmix > DML_MAXMIX) return GA_E_UNSUPPORTED;
+    if (d->ld < d->nmix * 10) return GA_E_BADARG;
+    if (!d->backward && !d->img_nchw && !d->img_nhwc) return GA_E_BADARG;
+    if (d->backward && (!d->dlogits || (!d->dimg_nhwc && !d->dimg_nchw))) return GA_E_BADARG;
+    const long npix = (long)d->N * d->H * d->W;
+    hipLaunchKernelGGL(dml_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)s, *d, npix);
+    return check_launch();
+}
+
+extern "C" int ga_maxpool2(const ga_maxpool2_desc* d, void* s) {
+    if (!d || !d->x || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if ((d->H | d->W) & 1) return GA_E_UNSUPPORTED;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && !d->y) return GA_E_BADARG;
+    if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    const long total4 = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
+    if (!d || !d->x_nchw || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->rep <= 0 || d->N % d->rep) return GA_E_BADARG;
+    if ((d->noise_nchw == nullptr) != (d->noise_coef == nullptr)) return GA_E_BADARG;
+    if (!d->backward && !d->y_nhwc) return GA_E_BADARG;
+    if (d->backward && (!d->dy_nhwc || !d->dx_nchw)) return GA_E_BADARG;
+    const long total = (long)d->N * d->C * d->H * d->W;
+    hipLaunchKernelGGL(image_io_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
+    return check_launch();
+}
+
+extern "C" int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* s) {
+    if (!x || !y || n <= 0) return GA_E_BADARG;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, y, n, alpha, beta);
+    return check_launch();
+}

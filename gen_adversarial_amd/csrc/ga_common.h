@@ -1,0 +1,43 @@
+// Shared device helpers for libga_ops (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ga_ops.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+namespace ga {
+
+extern thread_local hipError_t g_last_err;
+
+__device__ __forceinline__ float sigmoidf_(float u) { return 1.0f / (1.0f + expf(-u)); }
+
+// activation applied as a prologue (reference: torch.nn.SiLU / ELU / ReLU in NVAE cells and VGG)
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    switch (act) {
+        case GA_ACT_SILU: return u * sigmoidf_(u);
+        case GA_ACT_ELU:  return u > 0.0f ? u : expm1f(u);
+        case GA_ACT_RELU: return fmaxf(u, 0.0f);
+        default:          return u;
+    }
+}
+
+// d act(u) / du
+__device__ __forceinline__ float act_bwd(float u, int act) {
+    switch (act) {
+        case GA_ACT_SILU: { float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
+        case GA_ACT_ELU:  return u > 0.0f ? 1.0f : expf(u);
+        case GA_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+        default:          return 1.0f;
+    }
+}
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_err = e; return GA_E_LAUNCH; }
+    return GA_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace ga

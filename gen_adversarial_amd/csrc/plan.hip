@@ -1,0 +1,80 @@
+// Plan replay, timing helper and library metadata.
+#include "ga_common.h"
+#include <vector>
+
+namespace ga { thread_local hipError_t g_last_err = hipSuccess; }
+
+static int run_one(const ga_op& op, void* stream) {
+    switch (op.kind) {
+        case GA_OP_CONV:         return ga_conv2d(&op.u.conv, stream);
+        case GA_OP_DWCONV5:      return ga_dwconv5(&op.u.dw, stream);
+        case GA_OP_REDUCE:       return ga_rowchan_reduce(&op.u.red, stream);
+        case GA_OP_SE_EXCITE:    return ga_se_excite(&op.u.se, stream);
+        case GA_OP_SE_APPLY:     return ga_se_apply(&op.u.app, stream);
+        case GA_OP_BILINEAR_BWD: return ga_bilinear_up2_bwd(&op.u.bil, stream);
+        case GA_OP_SAMPLER:      return ga_sampler_mix(&op.u.smp, stream);
+        case GA_OP_DML:          return ga_dml_mean(&op.u.dml, stream);
+        case GA_OP_MAXPOOL:      return ga_maxpool2(&op.u.mp, stream);
+        case GA_OP_IMAGE_IO:     return ga_image_io(&op.u.io, stream);
+        case GA_OP_AXPBY:        return ga_axpby(op.u.ax.x, op.u.ax.y, op.u.ax.n, op.u.ax.alpha, op.u.ax.beta, stream);
+        default:                 return GA_E_UNSUPPORTED;
+    }
+}
+
+extern "C" int ga_plan_run(const ga_op* ops, int n, void* stream, int* failed_index) {
+    if (!ops || n < 0) return GA_E_BADARG;
+    for (int i = 0; i < n; ++i) {
+        const int rc = run_one(ops[i], stream);
+        if (rc != GA_OK) { if (failed_index) *failed_index = i; return rc; }
+    }
+    return GA_OK;
+}
+
+// Times `iters` replays of the plan with HIP events recorded on the plan's own stream.  When conv_ms is requested
+// every GA_OP_CONV launch of ONE extra replay is bracketed by its own event pair (per-launch device time).
+extern "C" int ga_plan_time(const ga_op* ops, int n, void* stream_, int iters, float* total_ms, float* conv_ms,
+                            long* conv_launches) {
+    if (!ops || n <= 0 || iters <= 0 || !total_ms) return GA_E_BADARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return GA_E_LAUNCH;
+    int rc = GA_OK;
+    hipEventRecord(e0, stream);
+    for (int it = 0; it < iters && rc == GA_OK; ++it) rc = ga_plan_run(ops, n, stream_, nullptr);
+    hipEventRecord(e1, stream);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    *total_ms = ms / (float)iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (rc != GA_OK) return rc;
+    if (conv_ms) {
+        std::vector<hipEvent_t> ev;
+        long nconv = 0;
+        for (int i = 0; i < n; ++i) if (ops[i].kind == GA_OP_CONV) ++nconv;
+        ev.resize(2 * nconv);
+        for (auto& e : ev) hipEventCreate(&e);
+        long k = 0;
+        for (int i = 0; i < n && rc == GA_OK; ++i) {
+            if (ops[i].kind == GA_OP_CONV) {
+                hipEventRecord(ev[2 * k], stream);
+                rc = run_one(ops[i], stream_);
+                hipEventRecord(ev[2 * k + 1], stream);
+                ++k;
+            } else {
+                rc = run_one(ops[i], stream_);
+            }
+        }
+        hipStreamSynchronize(stream);
+        double sum = 0.0;
+        for (long j = 0; j < k; ++j) { float t = 0.f; hipEventElapsedTime(&t, ev[2 * j], ev[2 * j + 1]); sum += t; }
+        for (auto& e : ev) hipEventDestroy(e);
+        *conv_ms = (float)sum;
+        if (conv_launches) *conv_launches = nconv;
+    }
+    return rc;
+}
+
+extern "C" const char* ga_last_hip_error(void) { return hipGetErrorString(ga::g_last_err); }
+extern "C" int ga_abi_version(void) { return 1; }
+extern "C" unsigned long ga_sizeof_op(void) { return sizeof(ga_op); }

@@ -1,0 +1,549 @@
+"""
+Host-side plan builder: turns (NVAE state dict, VGG state dict, row count) into two flat op lists — forward and
+backward-to-input — over caller-visible device buffers, replayed by libga_ops' ga_plan_run.
+
+What the plans compute (reference call chain):
+  EoTWrapper.forward (src/defenses/wrappers.py:15-24)              image_io: repeat + noise + clamp, NCHW->NHWC
+  MLVGMDefenseModel.__call__ (src/defenses/ours/abstract_models.py:161-193)
+  NVAEDefenseModel.purify (src/defenses/ours/models.py:160-274)    conv / dwconv5 / SE / sampler / DML ops
+  BaseClassificationModel.__call__ + Vgg (abstract_models.py:53-62; src/classifier/model.py:31-49)
+
+PyTorch is used for device memory and the current stream only; every arithmetic op of the path is a HIP kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from . import folding as F
+from .nvae_spec import DecCellSpec, EncCellSpec, NVAESpec, build_spec
+from .vgg_spec import VggSpec
+
+RES_SCALE = 0.1          # `0.1 * self.residual(x)` — architecture.py:133,183
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class Act:
+    """An NHWC activation buffer plus its (lazily allocated) gradient buffer."""
+
+    def __init__(self, eng: "Engine", n, h, w, c, name=''):
+        self.eng, self.n, self.h, self.w, self.c, self.name = eng, n, h, w, c, name
+        self.t = eng.alloc((n, h, w, c))
+        self._g = None
+        self.g_written = False
+        eng.acts[name] = self
+
+    @property
+    def g(self) -> torch.Tensor:
+        if self._g is None:
+            self._g = self.eng.alloc((self.n, self.h, self.w, self.c))
+        return self._g
+
+
+class Engine:
+    def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
+                 alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
+                 device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False):
+        if rows % rep:
+            raise ValueError('rows must be a multiple of the EoT repeat')
+        self.device = torch.device(device)
+        self.dry_run = dry_run
+        if self.device.type != 'cuda' and not dry_run:
+            raise RuntimeError('the HIP engine needs a GPU device; there is no CPU fallback '
+                               '(dry_run=True only builds and validates the plans)')
+        self.spec: NVAESpec = build_spec(nvae_cfg, resolution)
+        self.vspec = vgg_spec
+        self.rows, self.rep = rows, rep
+        self.alphas = [float(a) for a in alphas]
+        if len(self.alphas) != len(self.spec.groups):
+            raise ValueError(f'{len(self.spec.groups)} interpolation alphas expected, got {len(self.alphas)}')
+        self.temperature = float(temperature)
+        self.noise_eps = float(noise_eps)
+        self.need_backward = need_backward
+        self.bytes = 0
+        self.acts = {}                       # name -> Act (debugging / tests)
+        self._keep = []                      # weights etc.
+        self.fwd = L.Plan()
+        self.bwd = L.Plan()
+        self._bwd_steps = []                 # closures emitting backward ops, replayed in reverse
+        self._build(nvae_sd, vgg_sd)
+
+    # ------------------------------------------------------------------------------------------------ memory
+    def alloc(self, shape) -> torch.Tensor:
+        t = torch.zeros(shape, dtype=torch.float32, device=self.device)
+        self.bytes += t.numel() * 4
+        self._keep.append(t)     # plans hold raw pointers: every buffer lives as long as the engine
+        return t
+
+    def dev(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.to(self.device, dtype=torch.float32).contiguous()
+        self._keep.append(t)
+        self.bytes += t.numel() * 4
+        return t
+
+    def devd(self, d: dict) -> dict:
+        return {k: self.dev(v) for k, v in d.items()}
+
+    # ------------------------------------------------------------------------------------------------ op emitters
+    def conv(self, plan, name, x, w, y, *, cin=None, cout=None, bias=None, K=1, sn=1, sd=1, pad=0,
+             x2=None, pro_scale=None, pro_shift=None, pro_act=0, pro_per_row=0,
+             addend=None, addend_bcast=False, addend2=None, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0,
+             in_hw=None, out_hw=None, n=None):
+        """x, x2, y, addend*, dact_x are torch tensors [N,H,W,C] (or Act.t); shapes are taken from them."""
+        d = L.ConvDesc()
+        N, Hi, Wi, Cx = x.shape
+        d.x, d.ldx = _ptr(x), Cx
+        d.C1 = cin if cin is not None else Cx
+        if x2 is not None:
+            d.x2, d.ldx2, d.C2 = _ptr(x2), x2.shape[3], x2.shape[3]
+        d.w, d.bias = _ptr(w), _ptr(bias)
+        d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
+        No, Ho, Wo, Cy = y.shape
+        d.y, d.ldy = _ptr(y), Cy
+        d.Cout = cout if cout is not None else Cy
+        if addend is not None:
+            d.addend, d.ldadd, d.addend_bcast_n = _ptr(addend), addend.shape[-1], int(addend_bcast)
+        if addend2 is not None:
+            d.addend2, d.ldadd2 = _ptr(addend2), addend2.shape[-1]
+        if dact_x is not None:
+            d.dact_x, d.lddact = _ptr(dact_x), dact_x.shape[-1]
+            d.dact_scale, d.dact_shift, d.dact_act = _ptr(dact_scale), _ptr(dact_shift), dact_act
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo = N, Hi, Wi, Ho, Wo
+        d.KH = d.KW = K
+        d.sn, d.sd, d.pad = sn, sd, pad
+        assert No == N, (name, x.shape, y.shape)
+        assert w.numel() == d.Cout * K * K * (d.C1 + d.C2), (name, tuple(w.shape), d.Cout, K, d.C1, d.C2)
+        if sd == 1:
+            assert (Hi + 2 * pad - K) // sn + 1 == Ho, (name, Hi, Ho, K, sn, pad)
+        else:
+            assert Ho in (Hi * sd, Hi * sd - 1) or K == 1, (name, Hi, Ho)
+        plan.add(d, name)
+        return d
+
+    def grad_conv(self, name, x, w, target: Act, *, primary=None, **kw):
+        """Backward GEMM writing (or accumulating) into target.g; `primary` is an extra addend (identity skip)."""
+        addend, addend2 = primary, None
+        if target.g_written:
+            if addend is None:
+                addend = target.g
+            else:
+                addend2 = target.g
+        self.conv(self.bwd, name, x, w, target.g, addend=addend, addend2=addend2, **kw)
+        target.g_written = True
+
+    def se_forward(self, name, t: Act, wts, P):
+        """squeeze + excite; returns (gate, hid) buffers."""
+        n, c = t.n, t.c
+        hd = wts['se_w1'].shape[0]
+        m = self.alloc((n, c))
+        hid = self.alloc((n, hd))
+        gate = self.alloc((n, c))
+        r = L.ReduceDesc()
+        r.a, r.out, r.N, r.P, r.C, r.scale = _ptr(t.t), _ptr(m), n, P, c, 1.0 / P
+        self.fwd.add(r, f'{name}.squeeze')
+        e = L.SeExciteDesc()
+        e.m, e.w1, e.b1, e.w2, e.b2 = _ptr(m), _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
+        e.hid, e.gate, e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = _ptr(hid), _ptr(gate), n, c, hd, P, RES_SCALE, 0
+        self.fwd.add(e, f'{name}.excite')
+        return gate, hid
+
+    def se_backward(self, name, dout: torch.Tensor, t: Act, wts, gate, hid, P):
+        """emits d(gate) reduction + excite backward; returns the per-row prologue (scale, shift) for the next GEMM."""
+        n, c = t.n, t.c
+        dgate = self.scratch((n, c), f'dgate{c}')
+        ps = self.scratch((n, c), f'ps{c}')
+        pb = self.scratch((n, c), f'pb{c}')
+        r = L.ReduceDesc()
+        r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(dout), _ptr(t.t), _ptr(dgate), n, P, c, RES_SCALE
+        self.bwd.add(r, f'{name}.dgate')
+        e = L.SeExciteDesc()
+        e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
+        e.hid, e.gate, e.dgate, e.pro_scale, e.pro_shift = _ptr(hid), _ptr(gate), _ptr(dgate), _ptr(ps), _ptr(pb)
+        e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = n, c, wts['se_w1'].shape[0], P, RES_SCALE, 1
+        self.bwd.add(e, f'{name}.excite_bwd')
+        return ps, pb
+
+    def scratch(self, shape, key) -> torch.Tensor:
+        """Backward-only temporaries that die inside one cell: one buffer per (key, shape)."""
+        k = (key, tuple(shape))
+        if k not in self._scratch:
+            self._scratch[k] = self.alloc(shape)
+        return self._scratch[k]
+
+    # ------------------------------------------------------------------------------------------------ cells
+    def enc_cell(self, cell: EncCellSpec, x: Act) -> Act:
+        """ResidualCellEncoder (architecture.py:96-136): fwd ops now, bwd ops registered for later."""
+        wts = self.devd(F.fold_enc_cell(self.nvae_sd, cell))
+        n, h, w = x.n, x.h, x.w
+        st = 2 if cell.down else 1
+        ho, wo = h // st, w // st
+        t1 = Act(self, n, ho, wo, cell.cout, cell.prefix + '.t1')
+        t2 = Act(self, n, ho, wo, cell.cout, cell.prefix + '.t2')
+        out = Act(self, n, ho, wo, cell.cout, cell.prefix + '.out')
+        p = cell.prefix
+        self.conv(self.fwd, p + '.conv1', x.t, wts['w1'], t1.t, bias=wts['b1'], K=3, sn=st, pad=1,
+                  pro_scale=wts['pro_scale'], pro_shift=wts['pro_shift'], pro_act=L.GA_ACT_SILU)
+        self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, pad=1, pro_act=L.GA_ACT_SILU)
+        gate, hid = self.se_forward(p, t2, wts, ho * wo)
+        if cell.down:
+            sk = Act(self, n, ho, wo, cell.cout, p + '.skip')
+            self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sk.t, bias=wts['bs'], K=1, sn=2, pad=0, pro_act=L.GA_ACT_SILU)
+            skip_t = sk.t
+        else:
+            skip_t = x.t
+        a = L.SeApplyDesc()
+        a.skip, a.t, a.gate, a.out = _ptr(skip_t), _ptr(t2.t), _ptr(gate), _ptr(out.t)
+        a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = n, ho, wo, cell.cout, 0, RES_SCALE
+        self.fwd.add(a, p + '.merge')
+
+        def backward():
+            ps, pb = self.se_backward(p, out.g, t2, wts, gate, hid, ho * wo)
+            dt1 = self.scratch((n, ho, wo, cell.cout), 'enc_dt1')
+            self.conv(self.bwd, p + '.conv2^T', out.g, wts['w2_bwd'], dt1, K=3, pad=1,
+                      pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t1.t, dact_act=L.GA_ACT_SILU)
+            self.grad_conv(p + '.conv1^T', dt1, wts['w1_bwd'], x, K=3, sn=1, sd=st, pad=1,
+                           primary=None if cell.down else out.g,
+                           dact_x=x.t, dact_scale=wts['pro_scale'], dact_shift=wts['pro_shift'], dact_act=L.GA_ACT_SILU)
+            if cell.down:
+                self.grad_conv(p + '.skip^T', out.g, wts['ws_bwd'], x, K=1, sn=1, sd=2, pad=0,
+                               dact_x=x.t, dact_act=L.GA_ACT_SILU)
+        self._bwd_steps.append(backward)
+        return out
+
+    def dec_cell(self, cell: DecCellSpec, x: Act) -> Act:
+        """ResidualCellDecoder (architecture.py:139-186) with nearest-up folded into the depthwise read and the
+        SkipUp 1x1 applied before its bilinear interpolation."""
+        wts = self.devd(F.fold_dec_cell(self.nvae_sd, cell))
+        n, h, w = x.n, x.h, x.w
+        up = cell.up
+        H, W = (2 * h, 2 * w) if up else (h, w)
+        hid_c = cell.hidden
+        p = cell.prefix
+        t1 = Act(self, n, h, w, hid_c, p + '.t1')
+        t2 = Act(self, n, H, W, hid_c, p + '.t2')
+        t3 = Act(self, n, H, W, cell.cout, p + '.t3')
+        out = Act(self, n, H, W, cell.cout, p + '.out')
+        self.conv(self.fwd, p + '.pw1', x.t, wts['w1'], t1.t, bias=wts['b1'], K=1)
+        d = L.DwDesc()
+        d.x, d.w, d.bias, d.y = _ptr(t1.t), _ptr(wts['wd']), _ptr(wts['bd']), _ptr(t2.t)
+        d.N, d.H, d.W, d.C, d.pro_act, d.up2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
+        self.fwd.add(d, p + '.dw5')
+        self.conv(self.fwd, p + '.pw2', t2.t, wts['w2'], t3.t, bias=wts['b2'], K=1, pro_act=L.GA_ACT_SILU)
+        gate, hid = self.se_forward(p, t3, wts, H * W)
+        a = L.SeApplyDesc()
+        if up:
+            sl = Act(self, n, h, w, cell.cout, p + '.skip_low')
+            self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sl.t, bias=wts['bs'], K=1)
+            a.skip, a.skip_mode = _ptr(sl.t), 1
+        else:
+            a.skip, a.skip_mode = _ptr(x.t), 0
+        a.t, a.gate, a.out = _ptr(t3.t), _ptr(gate), _ptr(out.t)
+        a.N, a.H, a.W, a.C, a.res_scale = n, H, W, cell.cout, RES_SCALE
+        self.fwd.add(a, p + '.merge')
+
+        def backward():
+            ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W)
+            dt2 = self.scratch((n, H, W, hid_c), 'dec_dt2')
+            self.conv(self.bwd, p + '.pw2^T', out.g, wts['w2_bwd'], dt2, K=1,
+                      pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t2.t, dact_act=L.GA_ACT_SILU)
+            dt1 = self.scratch((n, h, w, hid_c), 'dec_dt1')
+            b = L.DwDesc()
+            b.x, b.w, b.dact_x, b.y = _ptr(dt2), _ptr(wts['wd_bwd']), _ptr(t1.t), _ptr(dt1)
+            b.N, b.H, b.W, b.C, b.dact_act, b.pool2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
+            self.bwd.add(b, p + '.dw5^T')
+            self.grad_conv(p + '.pw1^T', dt1, wts['w1_bwd'], x, K=1, primary=None if up else out.g)
+            if up:
+                dsl = self.scratch((n, h, w, cell.cout), 'dec_dsl')
+                bl = L.BilinearBwdDesc()
+                bl.dhigh, bl.dlow, bl.N, bl.h, bl.w, bl.C, bl.accumulate = _ptr(out.g), _ptr(dsl), n, h, w, cell.cout, 0
+                self.bwd.add(bl, p + '.bilinear^T')
+                self.grad_conv(p + '.skip^T', dsl, wts['ws_bwd'], x, K=1)
+        self._bwd_steps.append(backward)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ build
+    def _build(self, nvae_sd, vgg_sd):
+        self.nvae_sd = nvae_sd
+        self._scratch = {}
+        spec, R = self.spec, self.rows
+        H = spec.resolution
+        NL = spec.num_latent
+        dev = self.device
+
+        # ---- boundary buffers (caller-visible)
+        self.x_in = self.alloc((R // self.rep, 3, H, H))                    # NCHW images in [0,1]
+        self.noise = self.alloc((R, 3, H, H)) if self.noise_eps != 0.0 else None
+        self.noise_coef = self.alloc((R,)) if self.noise_eps != 0.0 else None
+        self.eps = [self.alloc((R, NL, gs.res, gs.res)) for gs in spec.groups]   # NCHW like the reference draws them
+        self.purified = self.alloc((R, 3, H, H))                            # NCHW
+        self.dx = self.alloc((R // self.rep, 3, H, H))
+
+        x0 = Act(self, R, H, H, 3, 'x0')
+        io = L.ImageIoDesc()
+        io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(self.x_in), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
+        io.N, io.C, io.H, io.W, io.rep, io.backward = R, 3, H, H, self.rep, 0
+        self.fwd.add(io, 'image_in')
+
+        def bwd_image():
+            b = L.ImageIoDesc()
+            b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(self.x_in), _ptr(self.noise), _ptr(self.noise_coef)
+            b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(self.dx)
+            b.N, b.C, b.H, b.W, b.rep, b.backward = R, 3, H, H, self.rep, 1
+            self.bwd.add(b, 'image_in^T')
+        self._bwd_steps.append(bwd_image)
+
+        # ---- stem: normalisation (x-0.5)/0.5 as prologue affine, then weight-normed 3x3 (model.py:106-107)
+        stem = self.devd(F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'))
+        two = self.dev(torch.full((3,), 2.0))
+        mone = self.dev(torch.full((3,), -1.0))
+        x = Act(self, R, H, H, spec.base_channels, 'stem')
+        self.conv(self.fwd, 'stem', x0.t, stem['w'], x.t, bias=stem['b'], K=3, pad=1, pro_scale=two, pro_shift=mone)
+        stem_out = x
+
+        def bwd_stem():
+            self.grad_conv('stem^T', stem_out.g, stem['w_bwd'], x0, K=3, pad=1,
+                           dact_x=x0.t, dact_scale=two, dact_shift=mone, dact_act=L.GA_ACT_NONE)
+        self._bwd_steps.append(bwd_stem)
+
+        for cell in spec.pre_cells:
+            x = self.enc_cell(cell, x)
+
+        stash: Dict[str, Act] = {}
+        for kind, payload in spec.enc_program:
+            if kind == 'stash':
+                stash[payload] = x
+            else:
+                x = self.enc_cell(payload, x)
+        x_top = x
+
+        # ---- encoder_0: ELU -> 1x1 -> ELU (model.py:184-187) and sampler_0:0 (3x3, mu half only: purify uses
+        #      dist_enc.mu alone, models.py:199-206)
+        C0 = spec.enc0_channels
+        g0 = spec.groups[0]
+        enc0 = self.devd(F.fold_wn_conv(nvae_sd, 'encoder_0.1'))
+        e0 = Act(self, R, g0.res, g0.res, C0, 'enc0')
+        self.conv(self.fwd, 'encoder_0', x_top.t, enc0['w'], e0.t, bias=enc0['b'], K=1, pro_act=L.GA_ACT_ELU)
+        s00 = self.devd(F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)))
+        muq0 = Act(self, R, g0.res, g0.res, NL, 'mu_q0')
+        self.conv(self.fwd, 'enc_sampler_0:0', e0.t, s00['w'], muq0.t, bias=s00['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
+        z = Act(self, R, g0.res, g0.res, NL, 'z0')
+        self._sampler_fwd('sample_0:0', muq0, None, self.eps[0], z, self.alphas[0])
+
+        # ---- combiner_0:0 on cat[const_prior, z0]: the prior half is row-independent -> folded into a broadcast addend
+        comb = F.fold_wn_conv(nvae_sd, 'decoder_combiners.combiner_0:0.conv')
+        wfull = F.wn_weight64(nvae_sd, 'decoder_combiners.combiner_0:0.conv')[:, :, 0, 0]       # [C0, C0+NL]
+        prior = nvae_sd['const_prior'].double()[0]                                               # [C0,h,w]
+        pc = torch.einsum('oc,chw->hwo', wfull[:, :C0], prior) + nvae_sd['decoder_combiners.combiner_0:0.conv.bias'].double()
+        pc = self.dev(pc.float().unsqueeze(0))                                                   # [1,h,w,C0]
+        wz = self.dev(wfull[:, C0:].float())
+        wz_bwd = self.dev(wfull[:, C0:].t().float())
+        x = Act(self, R, g0.res, g0.res, C0, 'comb_0:0')
+        self.conv(self.fwd, 'combiner_0:0', z.t, wz, x.t, K=1, addend=pc, addend_bcast=True)
+        comb0_out, z0 = x, z
+
+        def bwd_group0():
+            self.grad_conv('combiner_0:0^T', comb0_out.g, wz_bwd, z0, K=1)
+            self._sampler_bwd('sample_0:0^T', muq0, None, self.eps[0], z0, self.alphas[0], None)
+            self.grad_conv('enc_sampler_0:0^T', muq0.g, s00['w_bwd'], e0, K=3, pad=1, dact_x=e0.t, dact_act=L.GA_ACT_ELU)
+            self.grad_conv('encoder_0^T', e0.g, enc0['w_bwd'], x_top, K=1, dact_x=x_top.t, dact_act=L.GA_ACT_ELU)
+        group0_bwd = bwd_group0     # must run after every decoder-side use of the encoder features: registered below
+
+        dec_bwd_steps_start = len(self._bwd_steps)
+        # decoder-side backward steps are registered AFTER encoder ones so that they replay first (reverse order)
+        self._bwd_steps.append(group0_bwd)
+
+        for gs in spec.groups:
+            if gs.dec_cells:
+                for cell in gs.dec_cells:
+                    x = self.dec_cell(cell, x)
+                x = self._latent_group(gs, x, stash[f'{gs.s}:{gs.g}'])
+            if gs.g == spec.groups_per_scale[gs.s] - 1 and gs.s in spec.dec_up_cells:
+                x = self.dec_cell(spec.dec_up_cells[gs.s], x)
+
+        for cell in spec.post_cells:
+            x = self.dec_cell(cell, x)
+
+        # ---- to_logits (ELU -> 3x3, model.py:310-313) + DiscMixLogistic.mean + denormalise
+        tl = self.devd(F.fold_wn_conv(nvae_sd, 'to_logits.1'))
+        logits = Act(self, R, H, H, spec.logits_out, 'mix_logits')
+        post_out = x
+        self.conv(self.fwd, 'to_logits', x.t, tl['w'], logits.t, bias=tl['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
+        img = Act(self, R, H, H, 3, 'purified_nhwc')
+        dm = L.DmlDesc()
+        dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
+        dm.N, dm.H, dm.W, dm.backward = R, H, H, 0
+        self.fwd.add(dm, 'dml_mean')
+        self.dpurified = None    # optional external gradient on the purified image (NCHW), set by the caller
+
+        def bwd_dml():
+            b = L.DmlDesc()
+            b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
+            b.N, b.H, b.W, b.backward = R, H, H, 1
+            self.bwd.add(b, 'dml_mean^T')
+            self.grad_conv('to_logits^T', logits.g, tl['w_bwd'], post_out, K=3, pad=1, dact_x=post_out.t, dact_act=L.GA_ACT_ELU)
+        self._bwd_steps.append(bwd_dml)
+
+        # ---- classifier
+        self.logits = self._build_vgg(vgg_sd, img)
+
+        # ---- emit the backward plan: reverse registration order
+        if self.need_backward:
+            for step in reversed(self._bwd_steps):
+                step()
+        self.fwd.finalize()
+        self.bwd.finalize()
+        self._bwd_steps = None
+
+    # ------------------------------------------------------------------------------------------------ latents
+    def _sampler_fwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float):
+        d = L.SamplerDesc()
+        d.mu_q, d.ldq = _ptr(muq.t), muq.c
+        if p is not None:
+            d.p, d.ldp = _ptr(p.t), p.c
+        d.eps, d.eps_nchw, d.z = _ptr(eps), 1, _ptr(z.t)
+        d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
+        d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 0
+        self.fwd.add(d, name)
+
+    def _sampler_bwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float, dp: Optional[Act]):
+        d = L.SamplerDesc()
+        d.mu_q, d.ldq = _ptr(muq.t), muq.c
+        if p is not None:
+            d.p, d.ldp, d.dp = _ptr(p.t), p.c, _ptr(p.g)
+            p.g_written = True
+        d.eps, d.eps_nchw, d.dz, d.dmu_q = _ptr(eps), 1, _ptr(z.g), _ptr(muq.g)
+        muq.g_written = True
+        d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
+        d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 1
+        self.bwd.add(d, name)
+
+    def _latent_group(self, gs, x: Act, enc_feat: Act) -> Act:
+        """models.py:236-257 for one latent group: encoder/decoder parameters, interpolation, combiner."""
+        sd, R, NL, C, r = self.nvae_sd, self.rows, self.spec.num_latent, gs.channels, gs.res
+        key = f'{gs.s}:{gs.g}'
+        ec_w = self.devd(F.fold_wn_conv(sd, f'encoder_combiners.combiner_{key}.conv'))
+        es_w = self.devd(F.fold_wn_conv(sd, f'enc_sampler.sampler_{key}', out_slice=slice(0, NL)))
+        ds_w = self.devd(F.fold_wn_conv(sd, f'dec_sampler.sampler_{key}.1'))
+        cb = F.wn_weight64(sd, f'decoder_combiners.combiner_{key}.conv')[:, :, 0, 0]             # [C, C+NL]
+        cb_w = self.dev(cb.float())
+        cb_b = self.dev(sd[f'decoder_combiners.combiner_{key}.conv.bias'])
+        cbx_bwd = self.dev(cb[:, :C].t().float())
+        cbz_bwd = self.dev(cb[:, C:].t().float())
+        alpha = self.alphas[gs.latent_idx]
+        eps = self.eps[gs.latent_idx]
+
+        ec = Act(self, R, r, r, C, f'ec_{key}')
+        self.conv(self.fwd, f'enc_combiner_{key}', x.t, ec_w['w'], ec.t, bias=ec_w['b'], K=1, addend=enc_feat.t)
+        muq = Act(self, R, r, r, NL, f'mu_q_{key}')
+        self.conv(self.fwd, f'enc_sampler_{key}', ec.t, es_w['w'], muq.t, bias=es_w['b'], K=3, pad=1)
+        pp = Act(self, R, r, r, 2 * NL, f'p_{key}')
+        self.conv(self.fwd, f'dec_sampler_{key}', x.t, ds_w['w'], pp.t, bias=ds_w['b'], K=1, pro_act=L.GA_ACT_ELU)
+        z = Act(self, R, r, r, NL, f'z_{key}')
+        self._sampler_fwd(f'sample_{key}', muq, pp, eps, z, alpha)
+        out = Act(self, R, r, r, C, f'comb_{key}')
+        self.conv(self.fwd, f'combiner_{key}', x.t, cb_w, out.t, bias=cb_b, K=1, x2=z.t)
+
+        def backward():
+            self.grad_conv(f'combiner_{key}^T.z', out.g, cbz_bwd, z, K=1)
+            self.grad_conv(f'combiner_{key}^T.x', out.g, cbx_bwd, x, K=1)
+            self._sampler_bwd(f'sample_{key}^T', muq, pp, eps, z, alpha, pp)
+            self.grad_conv(f'dec_sampler_{key}^T', pp.g, ds_w['w_bwd'], x, K=1, dact_x=x.t, dact_act=L.GA_ACT_ELU)
+            self.grad_conv(f'enc_sampler_{key}^T', muq.g, es_w['w_bwd'], ec, K=3, pad=1)
+            self.grad_conv(f'enc_combiner_{key}^T', ec.g, ec_w['w_bwd'], x, K=1)
+            # the additive encoder feature receives d(ec) unchanged
+            if enc_feat.g_written:
+                a = L.AxpbyDesc()
+                a.x, a.y, a.n, a.alpha, a.beta = _ptr(ec.g), _ptr(enc_feat.g), ec.g.numel(), 1.0, 1.0
+            else:
+                a = L.AxpbyDesc()
+                a.x, a.y, a.n, a.alpha, a.beta = _ptr(ec.g), _ptr(enc_feat.g), ec.g.numel(), 1.0, 0.0
+                enc_feat.g_written = True
+            self.bwd.add(a, f'enc_feat_{key}.grad')
+        self._bwd_steps.append(backward)
+        return out
+
+    # ------------------------------------------------------------------------------------------------ classifier
+    def _build_vgg(self, vsd, img: Act) -> torch.Tensor:
+        """Vgg.forward on the purified image (abstract_models.py:188 -> :53-62): normalise (0.5,0.5) as prologue affine,
+        conv+BN folded, ReLU as the next op's prologue, max-pool on pre-activations."""
+        vs, R = self.vspec, self.rows
+        two = self.dev(torch.full((3,), 2.0))
+        mone = self.dev(torch.full((3,), -1.0))
+        cur, first = img, True
+        pending_pool = None
+        for op in vs.program:
+            if op[0] == 'conv':
+                _, i, cin, cout = op
+                wts = self.devd(F.fold_vgg_conv(vsd, i))
+                t = Act(self, R, cur.h, cur.w, cout, f'vgg.conv{i}')
+                src = cur
+                if first:
+                    self.conv(self.fwd, f'vgg.conv{i}', src.t, wts['w'], t.t, bias=wts['b'], K=3, pad=1, pro_scale=two, pro_shift=mone)
+
+                    def bwd(src=src, t=t, wts=wts, i=i):
+                        self.grad_conv(f'vgg.conv{i}^T', t.g, wts['w_bwd'], src, K=3, pad=1,
+                                       dact_x=src.t, dact_scale=two, dact_shift=mone, dact_act=L.GA_ACT_NONE)
+                else:
+                    self.conv(self.fwd, f'vgg.conv{i}', src.t, wts['w'], t.t, bias=wts['b'], K=3, pad=1, pro_act=L.GA_ACT_RELU)
+
+                    def bwd(src=src, t=t, wts=wts, i=i):
+                        self.grad_conv(f'vgg.conv{i}^T', t.g, wts['w_bwd'], src, K=3, pad=1, dact_x=src.t, dact_act=L.GA_ACT_RELU)
+                self._bwd_steps.append(bwd)
+                cur, first = t, False
+            else:
+                src = cur
+                pl = Act(self, R, src.h // 2, src.w // 2, src.c, src.name + '.pool')
+                m = L.MaxpoolDesc()
+                m.x, m.y, m.N, m.H, m.W, m.C, m.backward = _ptr(src.t), _ptr(pl.t), R, src.h, src.w, src.c, 0
+                self.fwd.add(m, pl.name)
+
+                def bwd(src=src, pl=pl):
+                    b = L.MaxpoolDesc()
+                    b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = _ptr(src.t), _ptr(pl.g), _ptr(src.g), R, src.h, src.w, src.c, 1
+                    self.bwd.add(b, pl.name + '^T')
+                    src.g_written = True
+                self._bwd_steps.append(bwd)
+                cur = pl
+        # head
+        f = cur.h
+        head = self.devd(F.fold_vgg_head(vsd, vs.feat_channels, f))
+        d = vs.head_dim
+        feat = cur
+        feat_flat = feat.t.view(R, 1, 1, f * f * feat.c)
+        h1 = Act(self, R, 1, 1, d, 'vgg.head1')
+        self.conv(self.fwd, 'vgg.head1', feat_flat, head['w_head'], h1.t, bias=head['b_head'], K=1, pro_act=L.GA_ACT_RELU)
+        out = Act(self, R, 1, 1, vs.n_classes, 'vgg.logits')
+        self.conv(self.fwd, 'vgg.head2', h1.t, head['w_out'], out.t, bias=head['b_out'], K=1, pro_act=L.GA_ACT_RELU)
+        self.dlogits = out.g
+        out.g_written = True
+
+        def bwd_head():
+            self.grad_conv('vgg.head2^T', out.g, head['w_out_bwd'], h1, K=1, dact_x=h1.t, dact_act=L.GA_ACT_RELU)
+            gflat = feat.g.view(R, 1, 1, f * f * feat.c)
+            assert not feat.g_written
+            self.conv(self.bwd, 'vgg.head1^T', h1.g, head['w_head_bwd'], gflat, K=1, dact_x=feat_flat, dact_act=L.GA_ACT_RELU)
+            feat.g_written = True
+        self._bwd_steps.append(bwd_head)
+        return out.t.view(R, vs.n_classes)
+
+    # ------------------------------------------------------------------------------------------------ run
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def forward(self):
+        if self.dry_run:
+            raise RuntimeError('dry-run engine: plans were built for validation only')
+        self.fwd.run(self.stream())
+
+    def backward(self):
+        if not self.need_backward:
+            raise RuntimeError('engine was built without a backward plan')
+        if self.dry_run:
+            raise RuntimeError('dry-run engine: plans were built for validation only')
+        self.bwd.run(self.stream())

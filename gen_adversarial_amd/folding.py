@@ -1,0 +1,157 @@
+"""
+Load-time weight preparation (host side, runs once per model): folds weight-norm and eval-mode batch-norm into
+the tensors the HIP kernels consume, and lays them out as include/ga_ops.h documents.
+
+Reference semantics being folded:
+  * weight_norm(Conv2d) — torch parametrization, w = g * v / ||v|| per output channel (keys
+    `parametrizations.weight.original0/1`; NVAE/modules/architecture.py:75,89,122,125,193,213; NVAE/model.py:106,186,
+    211,228,312)
+  * SyncBatchNorm(eps=1e-5) in .eval() (loading_utils.py:65) == y = x*s + t with s = gamma/sqrt(var+eps),
+    t = beta - mean*s (architecture.py:120,123,165-173)
+  * BatchNorm2d / BatchNorm1d of the VGG (src/classifier/model.py:37-45)
+All folds are computed in float64 and rounded once to float32.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+from .vgg_spec import adaptive_avgpool_matrix
+
+SD = Dict[str, torch.Tensor]
+
+
+def wn_weight64(sd: SD, prefix: str) -> torch.Tensor:
+    g = sd[f'{prefix}.parametrizations.weight.original0'].double()
+    v = sd[f'{prefix}.parametrizations.weight.original1'].double()
+    norm = v.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+    return v * (g / norm)
+
+
+def bn_affine64(sd: SD, prefix: str, eps: float = 1e-5) -> Tuple[torch.Tensor, torch.Tensor]:
+    s = sd[f'{prefix}.weight'].double() / torch.sqrt(sd[f'{prefix}.running_var'].double() + eps)
+    t = sd[f'{prefix}.bias'].double() - sd[f'{prefix}.running_mean'].double() * s
+    return s, t
+
+
+def conv_fwd_layout(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] -> [Cout][KH*KW*Cin] with k = (kh*KW+kw)*Cin + c."""
+    co = w.shape[0]
+    return w.permute(0, 2, 3, 1).reshape(co, -1).contiguous()
+
+
+def conv_bwd_layout(w: torch.Tensor) -> torch.Tensor:
+    """weights of the backward-to-input convolution: [Cin][KH*KW*Cout], spatially flipped."""
+    ci = w.shape[1]
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, -1).contiguous()
+
+
+def dw_layout(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
+    """[C,1,5,5] -> [25][C]."""
+    if flip:
+        w = w.flip(2, 3)
+    return w.reshape(w.shape[0], 25).t().contiguous()
+
+
+def f32(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+def fold_enc_cell(sd: SD, cell) -> dict:
+    p = cell.prefix
+    s0, t0 = bn_affine64(sd, f'{p}.residual.0')
+    w1 = wn_weight64(sd, f'{p}.residual.2')
+    b1 = sd[f'{p}.residual.2.bias'].double()
+    s1, t1 = bn_affine64(sd, f'{p}.residual.3')
+    w1f = w1 * s1.view(-1, 1, 1, 1)
+    b1f = b1 * s1 + t1
+    w2 = wn_weight64(sd, f'{p}.residual.5')
+    b2 = sd[f'{p}.residual.5.bias'].double()
+    out = {'pro_scale': f32(s0), 'pro_shift': f32(t0),
+           'w1': f32(conv_fwd_layout(w1f)), 'w1_bwd': f32(conv_bwd_layout(w1f)), 'b1': f32(b1f),
+           'w2': f32(conv_fwd_layout(w2)), 'w2_bwd': f32(conv_bwd_layout(w2)), 'b2': f32(b2)}
+    out.update(_se(sd, f'{p}.residual.6'))
+    if cell.down:
+        ws = wn_weight64(sd, f'{p}.skip_connection.conv')
+        out['ws'] = f32(conv_fwd_layout(ws))
+        out['ws_bwd'] = f32(conv_bwd_layout(ws))
+        out['bs'] = f32(sd[f'{p}.skip_connection.conv.bias'].double())
+    return out
+
+
+def _se(sd: SD, prefix: str) -> dict:
+    return {'se_w1': f32(sd[f'{prefix}.linear_1.weight']), 'se_b1': f32(sd[f'{prefix}.linear_1.bias']),
+            'se_w2': f32(sd[f'{prefix}.linear_2.weight']), 'se_b2': f32(sd[f'{prefix}.linear_2.bias'])}
+
+
+def fold_dec_cell(sd: SD, cell) -> dict:
+    p, o = cell.prefix, cell.ridx
+    s0, t0 = bn_affine64(sd, f'{p}.residual.{o + 0}')
+    w1 = sd[f'{p}.residual.{o + 1}.weight'].double()[:, :, 0, 0]             # [hid, cin]
+    s1, t1 = bn_affine64(sd, f'{p}.residual.{o + 2}')
+    w1f = s1.view(-1, 1) * w1 * s0.view(1, -1)
+    b1f = s1 * (w1 @ t0) + t1
+    wd = sd[f'{p}.residual.{o + 4}.weight'].double()                         # [hid,1,5,5]
+    s2, t2 = bn_affine64(sd, f'{p}.residual.{o + 5}')
+    wdf = wd * s2.view(-1, 1, 1, 1)
+    w2 = sd[f'{p}.residual.{o + 7}.weight'].double()[:, :, 0, 0]             # [cout, hid]
+    s3, t3 = bn_affine64(sd, f'{p}.residual.{o + 8}')
+    w2f = s3.view(-1, 1) * w2
+    out = {'w1': f32(w1f), 'w1_bwd': f32(w1f.t()), 'b1': f32(b1f),
+           'wd': f32(dw_layout(wdf)), 'wd_bwd': f32(dw_layout(wdf, flip=True)), 'bd': f32(t2),
+           'w2': f32(w2f), 'w2_bwd': f32(w2f.t()), 'b2': f32(t3)}
+    out.update(_se(sd, f'{p}.residual.{o + 9}'))
+    if cell.up:
+        ws = wn_weight64(sd, f'{p}.skip_connection.conv')[:, :, 0, 0]
+        out['ws'] = f32(ws)
+        out['ws_bwd'] = f32(ws.t())
+        out['bs'] = f32(sd[f'{p}.skip_connection.conv.bias'].double())
+    return out
+
+
+def fold_wn_conv(sd: SD, prefix: str, out_slice: slice = None, in_slice: slice = None) -> dict:
+    w = wn_weight64(sd, prefix)
+    b = sd[f'{prefix}.bias'].double()
+    if out_slice is not None:
+        w, b = w[out_slice], b[out_slice]
+    if in_slice is not None:
+        w = w[:, in_slice]
+    return {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(b)}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# VGG
+# ---------------------------------------------------------------------------------------------------------------
+
+def fold_vgg_conv(sd: SD, i: int) -> dict:
+    w = sd[f'model.features.{i}.weight'].double()
+    b = sd[f'model.features.{i}.bias'].double()
+    s, t = bn_affine64(sd, f'model.features.{i + 1}')
+    wf = w * s.view(-1, 1, 1, 1)
+    return {'w': f32(conv_fwd_layout(wf)), 'w_bwd': f32(conv_bwd_layout(wf)), 'b': f32(b * s + t)}
+
+
+def fold_vgg_head(sd: SD, feat_channels: int, feat_hw: int, chunk: int = 2048) -> dict:
+    """
+    AdaptiveAvgPool2d((7,7)) + flatten + Linear(d,d,bias=False) + BatchNorm1d folded into one [d][f*f*C] matrix whose
+    input is the NHWC-flattened f x f feature map (exact: the pool is linear).  src/classifier/model.py:39-45.
+    """
+    w0 = sd['model.classifier.0.weight']                                     # [d, C*49], input index c*49 + oh*7 + ow
+    d = w0.shape[0]
+    C, f = feat_channels, feat_hw
+    A = adaptive_avgpool_matrix(f, 7)                                        # [7, f]
+    K = torch.einsum('ai,bj->abij', A, A).reshape(49, f * f)                 # [(oh,ow), (ih,iw)]
+    s, t = bn_affine64(sd, 'model.classifier.1')
+    big = d * C * 49 > (1 << 26)
+    Kc = K.float() if big else K
+    out = torch.empty(d, f * f * C, dtype=torch.float32)
+    for r0 in range(0, d, chunk):
+        blk = w0[r0:r0 + chunk].reshape(-1, C, 49)
+        blk = blk.float() if big else blk.double()
+        fold = torch.matmul(blk, Kc)                                         # [r, C, f*f]
+        fold = fold.permute(0, 2, 1).reshape(blk.shape[0], f * f * C)        # NHWC flatten: (ih*f+iw)*C + c
+        out[r0:r0 + chunk] = (fold * s[r0:r0 + chunk].to(fold.dtype).view(-1, 1)).float()
+    w3 = sd['model.classifier.3.weight']
+    return {'w_head': out, 'w_head_bwd': out.t().contiguous(), 'b_head': f32(t),
+            'w_out': f32(w3), 'w_out_bwd': f32(w3.t()), 'b_out': f32(sd['model.classifier.3.bias'])}

@@ -1,0 +1,221 @@
+/*
+ * ga_ops.h — C-ABI of libga_ops.so: the MI355X (gfx950) kernels of the purification-under-attack hot path.
+ *
+ * The reference (SerezD/gen_adversarial) is pure Python on PyTorch and has no FFI for this path; its only native
+ * ABI is the pybind pair `fused_bias_act` / `upfirdn2d` of the StyleGAN ops
+ * (src/mlvgms_autoencoders/StyleGan_E4E/stylegan2/op/fused_bias_act.cpp:11-20, upfirdn2d.cpp:12-22), which is not on
+ * the NVAE path.  The entry points below are therefore the boundary SURVEY.md §8(b) prescribes: what a maintainer
+ * would bind (ctypes / torch custom op) in place of the ATen calls made by the reference modules cited per op.
+ *
+ * Conventions
+ *   - every tensor is fp32 and lives in device memory owned by the caller; nothing is allocated inside;
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) at ((n*H+h)*W+w)*ld + c, ld >= C is the channel pitch;
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*) and returns immediately;
+ *   - return value 0 = enqueued, <0 = rejected (GA_E_*), nothing launched;
+ *   - "prologue" = element-wise function applied to an operand as it is read, "epilogue" = applied to the result
+ *     before it is written.  Activations are always prologues of the consuming op so that the tensor kept for the
+ *     backward pass is the pre-activation one.
+ */
+#ifndef GA_OPS_H
+#define GA_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GA_OK            0
+#define GA_E_BADARG     -1   /* null pointer / non-positive size */
+#define GA_E_ALIGN      -2   /* pointer or pitch not aligned as the op requires */
+#define GA_E_UNSUPPORTED -3  /* shape outside what the kernel implements */
+#define GA_E_LAUNCH     -4   /* hipLaunch failed (see ga_last_hip_error) */
+
+enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3 };
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ga_conv2d — dense convolution as an fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
+ * Serves, with different descriptors, every dense contraction on the path, forward and backward-to-input:
+ *   weight-normed 3x3 / 1x1 convs of ResidualCellEncoder, SkipDown, EncCombinerCell, DecCombinerCell, samplers,
+ *   encoder_0, to_logits (NVAE/modules/architecture.py:64-218, NVAE/model.py:97-315), the 1x1 convs of
+ *   ResidualCellDecoder / SkipUp (architecture.py:85-93,139-186), VGG convs and the projector head
+ *   (src/classifier/model.py:31-49), i.e. what the reference runs as aten::conv2d / aten::linear.
+ *
+ *   y[n,ho,wo,co] = epi( bias[co] + sum_{kh,kw,c} w[co][(kh*KW+kw)*(C1+C2)+c] * in(n, hi, wi, c) )
+ *   hi = (ho*sn - pad + kh) / sd   (tap skipped unless divisible and 0<=hi<Hi; same for wi)
+ *   in(.,c) = c <  C1 : act_pro( pro_scale[c]*x[.,c] + pro_shift[c] )      (zero outside the image, after act)
+ *             c >= C1 : x2[., c-C1]                                        (concat-free second source)
+ *   epi(v)  = v * act'_dact( dact_scale[co]*dact_x[n,ho,wo,co] + dact_shift[co] ) * dact_scale[co]   (if dact_x)
+ *             + addend[(bcast ? (ho,wo) : (n,ho,wo)), co]                                             (if addend)
+ *             + addend2[n,ho,wo,co]                                                                   (if addend2)
+ * sn/sd: (stride,1) = forward strided conv; (1,stride) = its transpose (backward-to-input) with flipped weights.
+ * addend may alias y (in-place accumulation of a gradient).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ga_conv_desc {
+    const float* x;          int ldx;      /* [N,Hi,Wi,ldx], channels [0,C1) used */
+    const float* x2;         int ldx2;     /* optional [N,Hi,Wi,ldx2], channels [0,C2) */
+    const float* w;                        /* [Cout][KH*KW*(C1+C2)] */
+    const float* bias;                     /* [Cout] or NULL */
+    const float* pro_scale;                /* [C1] or [N][C1] (pro_per_row) or NULL */
+    const float* pro_shift;
+    const float* addend;     int ldadd;    /* optional, may alias y */
+    const float* addend2;    int ldadd2;   /* optional second addend [N,Ho,Wo,ldadd2], may alias y */
+    const float* dact_x;     int lddact;   /* optional [N,Ho,Wo,lddact] */
+    const float* dact_scale;               /* [Cout] or NULL */
+    const float* dact_shift;
+    float* y;                int ldy;      /* [N,Ho,Wo,ldy] */
+    int N, Hi, Wi, C1, C2;
+    int Ho, Wo, Cout;
+    int KH, KW, sn, sd, pad;
+    int pro_act, pro_per_row;
+    int dact_act;
+    int addend_bcast_n;                    /* addend is [Ho,Wo,ldadd], shared by all n */
+    int tile;                              /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32 (M x N) */
+} ga_conv_desc;
+int ga_conv2d(const ga_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * ga_dwconv5 — depthwise 5x5, pad 2 (the middle of ResidualCellDecoder, architecture.py:169), LDS-tiled, HBM-bound.
+ *   forward : y = bias + dw5( act_pro(x) )              x may be half resolution (`up2`: nearest x2 folded into the
+ *                                                        read — nn.UpsamplingNearest2d commutes with the 1x1/BN/SiLU
+ *                                                        in front of it, architecture.py:162-168)
+ *   backward: y = dw5_flipped(x) * act'_dact(dact_x)    with `pool2`: the 2x2 sum that is the adjoint of `up2`
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ga_dwconv5_desc {
+    const float* x;      /* [N,Hs,Ws,C]; Hs = H/2 if up2 else H */
+    const float* w;      /* [25][C] tap-major (already flipped for the backward use) */
+    const float* bias;   /* [C] or NULL */
+    const float* dact_x; /* optional, [N,Ho,Wo,C] at OUTPUT resolution */
+    float* y;            /* [N,Ho,Wo,C]; Ho = H/2 if pool2 else H */
+    int N, H, W, C;      /* H,W = resolution at which the 5x5 window slides */
+    int pro_act, dact_act, up2, pool2;
+} ga_dwconv5_desc;
+int ga_dwconv5(const ga_dwconv5_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Squeeze-and-excite (architecture.py:37-61) split into its reduction, its two tiny FCs and the residual merge.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)      (squeeze: scale=1/HW; d(gate): b = t, scale = 0.1) */
+typedef struct ga_rowchan_reduce_desc {
+    const float* a; const float* b; float* out;
+    int N, P, C; float scale;
+} ga_rowchan_reduce_desc;
+int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* stream);
+
+/* forward : hid[n,:] = w1 m[n,:] + b1 (pre-ReLU, kept) ; gate[n,:] = sigmoid(w2 relu(hid) + b2)
+ * backward: given dgate (already d/d gate), writes pro_scale[n,c] = res_scale*gate, pro_shift[n,c] = dm[n,c]/P where
+ *           dm is the gradient w.r.t. the squeezed mean — the per-row affine prologue of the next backward GEMM. */
+typedef struct ga_se_excite_desc {
+    const float* m;        /* fwd: [N,C] squeezed mean */
+    const float* w1; const float* b1;   /* [Hd][C], [Hd] */
+    const float* w2; const float* b2;   /* [C][Hd], [C] */
+    float* hid;            /* [N,Hd] (written fwd, read bwd) */
+    float* gate;           /* [N,C]  (written fwd, read bwd) */
+    const float* dgate;    /* bwd only */
+    float* pro_scale; float* pro_shift;  /* bwd only, [N,C] */
+    int N, C, Hd, P; float res_scale; int backward;
+} ga_se_excite_desc;
+int ga_se_excite(const ga_se_excite_desc* d, void* stream);
+
+/* out[n,h,w,c] = skip(n,h,w,c) + res_scale * gate[n,c] * t[n,h,w,c]
+ * skip_mode 0: skip is [N,H,W,C]; 1: skip is [N,H/2,W/2,C] read through bilinear x2, align_corners=True
+ * (SkipUp, architecture.py:91-93; the 1x1 conv commutes with the interpolation and is applied at low resolution). */
+typedef struct ga_se_apply_desc {
+    const float* skip; const float* t; const float* gate; float* out;
+    int N, H, W, C; int skip_mode; float res_scale;
+} ga_se_apply_desc;
+int ga_se_apply(const ga_se_apply_desc* d, void* stream);
+
+/* adjoint of bilinear x2 (align_corners=True): dlow[n,h,w,c] (+)= sum over the high-res pixels it feeds */
+typedef struct ga_bilinear_up2_bwd_desc {
+    const float* dhigh; float* dlow; int N, h, w, C; int accumulate;
+} ga_bilinear_up2_bwd_desc;
+int ga_bilinear_up2_bwd(const ga_bilinear_up2_bwd_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Latent interpolation of NVAEDefenseModel.purify (src/defenses/ours/models.py:199-206, 246-250) with
+ * Normal/soft_clamp (NVAE/modules/distributions.py:20-48):
+ *   enc_mu = 5 tanh((mu_p + mu_q)/5);  dec_mu = 5 tanh(mu_p/5);  sigma = temp * exp(5 tanh(logsig_p/5))
+ *   z = (1-alpha) enc_mu + alpha (eps*sigma + dec_mu)
+ * mu_q: [N,h,w,ldq] channels [0,NL); p: [N,h,w,ldp] = (mu_p | logsig_p) or NULL for the first group (prior N(0,1)).
+ * eps is read in the reference's NCHW order [N,NL,h,w] when eps_nchw, else NHWC.
+ * backward (dz given): writes dmu_q [N,h,w,ldq] and dp [N,h,w,ldp].
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ga_sampler_desc {
+    const float* mu_q; int ldq;
+    const float* p;    int ldp;
+    const float* eps;  int eps_nchw;
+    float* z;          /* fwd out [N,h,w,NL] */
+    const float* dz;   /* bwd in */
+    float* dmu_q; float* dp;   /* bwd out */
+    int N, h, w, NL; float alpha, one_minus_alpha, temp; int backward;   /* one_minus_alpha = (float)(1.0 - alpha_double) */
+} ga_sampler_desc;
+int ga_sampler_mix(const ga_sampler_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * DiscMixLogistic(...).mean() + denormalisation (distributions.py:103-129, 231-254; models.py:271-274).
+ * logits [N,H,W,ld] with channel layout (nmix | nmix x (3 mu, 3 log_scale, 3 coeff)).
+ * forward writes the purified image twice: NCHW [N,3,H,W] (API output) and NHWC [N,H,W,3] (classifier input).
+ * backward: dimg given as NHWC [N,H,W,3] (+ optional NCHW addend), writes dlogits [N,H,W,ld] (all ld channels).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct ga_dml_desc {
+    const float* logits; int ld; int nmix;
+    float* img_nchw; float* img_nhwc;
+    const float* dimg_nhwc; const float* dimg_nchw; float* dlogits;
+    int N, H, W; int backward;
+} ga_dml_desc;
+int ga_dml_mean(const ga_dml_desc* d, void* stream);
+
+/* 2x2/2 max pool on pre-activation maps (ReLU commutes with max), torchvision VGG 'M' entries. backward routes dy to
+ * the first maximal element in (h,w) scan order. */
+typedef struct ga_maxpool2_desc {
+    const float* x; float* y; const float* dy; float* dx; int N, H, W, C; int backward;
+} ga_maxpool2_desc;
+int ga_maxpool2(const ga_maxpool2_desc* d, void* stream);
+
+/* Image boundary: NCHW [N,3,H,W] in [0,1] <-> NHWC with MLVGMDefenseModel.add_gaussian_noise
+ * (abstract_models.py:129-143): out = clamp(x[n / rep] + noise * noise_coef[n], 0, 1); `rep` folds EoTWrapper's
+ * x.repeat(eot,1,1,1) (wrappers.py:20).  noise may be NULL.  backward: dx[n,c,h,w] = dy_nhwc * 1[0 <= pre <= 1]. */
+typedef struct ga_image_io_desc {
+    const float* x_nchw;      /* [N/rep,C,H,W] */
+    const float* noise_nchw;  /* [N,C,H,W] or NULL */
+    const float* noise_coef;  /* [N] = eps / ||noise_n||_2, or NULL */
+    float* y_nhwc;            /* fwd out [N,H,W,C] */
+    const float* dy_nhwc;     /* bwd in  [N,H,W,C] */
+    float* dx_nchw;           /* bwd out [N/rep,C,H,W]: sum over the rep rows of each image */
+    int N, C, H, W; int rep; int backward;
+} ga_image_io_desc;
+int ga_image_io(const ga_image_io_desc* d, void* stream);
+
+/* y = alpha*x + beta*y over n floats */
+int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Plans: a forward or backward pass is a flat list of the ops above, built once on the host and replayed by ONE call.
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
+                  GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
+                  GA_OP_AXPBY = 11 };
+typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
+typedef struct ga_op {
+    int kind;
+    int _pad;
+    union {
+        ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
+        ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
+        ga_axpby_desc ax;
+    } u;
+} ga_op;
+/* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */
+int ga_plan_run(const ga_op* ops, int n, void* stream, int* failed_index);
+
+/* timing helper for bench.py: runs the plan `iters` times between two hipEvents recorded on `stream`, returns ms,
+ * and when conv_ms != NULL also the summed duration of the GA_OP_CONV launches (per-op events). */
+int ga_plan_time(const ga_op* ops, int n, void* stream, int iters, float* total_ms, float* conv_ms, long* conv_launches);
+
+const char* ga_last_hip_error(void);
+int ga_abi_version(void);
+unsigned long ga_sizeof_op(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

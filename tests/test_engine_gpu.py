@@ -1,0 +1,150 @@
+"""
+GPU parity of the whole hot path (EoT repeat -> noise -> NVAE purify -> VGG -> logits, and backward-to-input)
+against (a) the golden vectors produced by the reference and (b) the CPU oracle on fresh seeded inputs.
+Tolerance: 1e-3 absolute on purified images / logits / input-gradients, as BASELINE.json's north_star states
+("within 1e-3 fp32"); observed errors are ~1e-5 and are asserted at 2e-4 to catch regressions early.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from conftest import golden_cfg   # noqa: E402
+from gen_adversarial_amd.engine import Engine   # noqa: E402
+from gen_adversarial_amd.nvae_spec import build_spec, init_nvae_state_dict   # noqa: E402
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   # noqa: E402
+
+DEV = 'cuda:0'
+TOL_SPEC = 1e-3
+TOL = 2e-4
+CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive']
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _err(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def _setup(g, rows, rep):
+    cfg, res = golden_cfg(g)
+    sd = init_nvae_state_dict(cfg, res, int(g['nvae_seed']))
+    vspec = build_vgg_spec(int(g['n_classes']), int(g['width_div']))
+    vsd = init_vgg_state_dict(int(g['n_classes']), int(g['width_div']), int(g['vgg_seed']))
+    alphas = [float(a) * float(g['attenuation']) for a in g['alphas']]
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, temperature=0.6,
+                 noise_eps=float(g['noise_eps']), device=DEV)
+    return eng
+
+
+def _load_noise(eng, noise, eps):
+    if eng.noise is not None:
+        n = noise.to(DEV)
+        eng.noise.copy_(n)
+        eng.noise_coef.copy_(eps / n.flatten(1).norm(dim=1))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_defender_matches_reference_golden(name, golden_cases):
+    g = golden_cases[name]
+    x = _t(g['x'])
+    eng = _setup(g, rows=x.shape[0], rep=1)
+    eng.x_in.copy_(x.to(DEV))
+    for i, e in enumerate(eng.eps):
+        e.copy_(_t(g[f'eps_{i}']).to(DEV))
+    _load_noise(eng, _t(g['input_noise']), float(g['noise_eps']))
+    eng.forward()
+    torch.cuda.synchronize()
+    e_p, e_l = _err(eng.purified, _t(g['purified'])), _err(eng.logits, _t(g['logits']))
+    eng.dlogits.view_as(eng.logits).copy_(_t(g['cotangent']).to(DEV))
+    eng.backward()
+    torch.cuda.synchronize()
+    e_g = _err(eng.dx, _t(g['grad_x']))
+    gmax = float(np.abs(g['grad_x']).max())
+    print(f'{name}: purified {e_p:.2e} logits {e_l:.2e} grad {e_g:.2e} (|grad|max {gmax:.2e})')
+    assert e_p < TOL and e_l < TOL and e_g < TOL * max(1.0, gmax) and TOL <= TOL_SPEC
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_eot_ce_gradient_matches_reference_golden(name, golden_cases):
+    g = golden_cases[name]
+    eot = int(g['eot_steps'])
+    eng = _setup(g, rows=eot, rep=eot)
+    eng.x_in.copy_(_t(g['x'][:1]).to(DEV))
+    for i, e in enumerate(eng.eps):
+        e.copy_(_t(g[f'eot_eps_{i}']).to(DEV))
+    _load_noise(eng, _t(g['eot_noise']), float(g['noise_eps']))
+    eng.forward()
+    logits = eng.logits.clone().requires_grad_(True)
+    mean = logits.mean(dim=0, keepdim=True)                   # EoTWrapper: mean over the repeats
+    assert _err(mean, _t(g['eot_logits'])) < TOL
+    loss = torch.nn.functional.cross_entropy(mean, mean.argmax(dim=1))
+    (gl,) = torch.autograd.grad(loss, [logits])
+    eng.dlogits.view_as(eng.logits).copy_(gl)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert _err(eng.dx, _t(g['eot_ce_grad'])) < TOL
+
+
+def test_multiple_backwards_per_forward_and_determinism(golden_cases):
+    """attacks call backward several times on one forward (retain_graph, untargeted.py:529-535)."""
+    g = golden_cases['A_cos07']
+    x = _t(g['x'])
+    eng = _setup(g, rows=x.shape[0], rep=1)
+    eng.x_in.copy_(x.to(DEV))
+    for i, e in enumerate(eng.eps):
+        e.copy_(_t(g[f'eps_{i}']).to(DEV))
+    eng.forward()
+    cot = _t(g['cotangent']).to(DEV)
+    eng.dlogits.view_as(eng.logits).copy_(cot)
+    eng.backward()
+    g1 = eng.dx.clone()
+    eng.dlogits.view_as(eng.logits).copy_(2 * cot)
+    eng.backward()
+    g2 = eng.dx.clone()
+    eng.dlogits.view_as(eng.logits).copy_(cot)
+    eng.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.dx, g1), 'backward is not bitwise reproducible'
+    assert _err(g2, 2 * g1) < 1e-6
+
+
+def test_against_oracle_on_fresh_inputs():
+    """oracle (CPU) vs HIP on a mid-size config with 32-multiple channels (vectorised paths, every tile shape)."""
+    from oracle import defender_oracle as D
+    cfg = {'initial_channels': 16, 'num_pre-post_process_blocks': 2, 'num_pre-post_process_cells': 2, 'num_scales': 3,
+           'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 2,
+           'num_latent_per_group': 20, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+    res = (3, 64, 64)
+    spec = build_spec(cfg, res)
+    sd = init_nvae_state_dict(cfg, res, 3)
+    vspec = build_vgg_spec(100, 8)
+    vsd = init_vgg_state_dict(100, 8, 4)
+    rows, rep = 8, 4
+    alphas = [0.7 * i / (len(spec.groups) - 1) for i in range(len(spec.groups))]
+    gen = torch.Generator().manual_seed(0)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, 20, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    xr = imgs.clone().requires_grad_(True)
+    logits, purified = D.nvae_defender(sd, spec, vsd, vspec, xr.repeat_interleave(rep, dim=0), alphas, eps,
+                                       torch.randn(rows, 3, 64, 64, generator=gen), 0.0)
+    cot = torch.randn(logits.shape, generator=gen)
+    (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
+
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV)
+    eng.x_in.copy_(imgs.to(DEV))
+    for b, e in zip(eng.eps, eps):
+        b.copy_(e.to(DEV))
+    eng.forward()
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    torch.cuda.synchronize()
+    e_p, e_l, e_g = _err(eng.purified, purified), _err(eng.logits, logits), _err(eng.dx, gx)
+    print(f'oracle parity: purified {e_p:.2e} logits {e_l:.2e} grad {e_g:.2e} (|grad|max {gx.abs().max():.2e})')
+    assert e_p < TOL and e_l < TOL and e_g < TOL * max(1.0, gx.abs().max().item())

@@ -1,0 +1,384 @@
+"""
+GPU parity tests, one per C entry point of include/ga_ops.h: each kernel against the same op written with plain
+PyTorch fp32 on the CPU (forward and, through autograd, backward-to-input).  Tolerances are stated per test;
+the dense contractions are exact-fp32 fma chains whose summation order differs from ATen's, hence ~1e-5 relative.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd import _lib as L   # noqa: E402
+
+DEV = 'cuda:0'
+ACTS = {0: lambda u: u, 1: F.silu, 2: F.elu, 3: F.relu}
+
+
+def nhwc(t):   # NCHW cpu -> NHWC gpu
+    return t.permute(0, 2, 3, 1).contiguous().to(DEV)
+
+
+def nchw(t):   # NHWC gpu -> NCHW cpu
+    return t.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def close(a, b, tol, what=''):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * max(1.0, ref), f'{what}: max err {err:.3e} (ref max {ref:.3e})'
+
+
+def fwd_w(w):
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(DEV)
+
+
+def bwd_w(w):
+    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(w.shape[1], -1).contiguous().to(DEV)
+
+
+def run_conv(x, w, y, K, sn=1, sd=1, pad=0, tile=0, **kw):
+    d = L.ConvDesc()
+    d.x, d.ldx, d.C1 = x.data_ptr(), x.shape[3], x.shape[3]
+    d.w, d.y, d.ldy, d.Cout = w.data_ptr(), y.data_ptr(), y.shape[3], y.shape[3]
+    d.N, d.Hi, d.Wi = x.shape[0], x.shape[1], x.shape[2]
+    d.Ho, d.Wo = y.shape[1], y.shape[2]
+    d.KH = d.KW = K
+    d.sn, d.sd, d.pad, d.tile = sn, sd, pad, tile
+    keep = []
+    for k, v in kw.items():
+        if isinstance(v, torch.Tensor):
+            keep.append(v)
+            setattr(d, k, v.data_ptr())
+        else:
+            setattr(d, k, v)
+    L.run(d)
+    torch.cuda.synchronize()
+    return d
+
+
+CONV_CASES = [
+    # N, H, Cin, Cout, K, stride, pro_act, affine, tile
+    (2, 8, 32, 40, 3, 1, 1, True, 0),
+    (2, 8, 32, 130, 3, 2, 1, True, 1),
+    (3, 6, 3, 16, 3, 1, 0, True, 0),       # stem-like, non-vectorised path
+    (2, 8, 20, 100, 3, 1, 2, False, 2),
+    (2, 16, 48, 64, 1, 1, 0, False, 3),
+    (2, 8, 160, 33, 1, 2, 1, False, 4),
+    (5, 4, 8, 8, 3, 1, 1, True, 1),
+    (2, 4, 6, 12, 1, 1, 3, False, 0),      # Cin % 4 != 0
+    (1, 32, 36, 257, 3, 1, 1, True, 1),
+    (3, 32, 8, 16, 3, 2, 1, True, 0),
+    (3, 32, 8, 16, 3, 2, 1, True, 1),
+    (3, 32, 8, 16, 3, 2, 1, True, 3),
+    (3, 32, 8, 16, 3, 1, 1, True, 4),
+    (3, 32, 8, 16, 3, 2, 0, False, 4),
+    (1, 32, 8, 16, 3, 2, 0, False, 4),
+    (1, 16, 8, 16, 3, 2, 0, False, 4),
+    (1, 16, 32, 16, 3, 2, 0, False, 4),
+]
+
+
+@pytest.mark.parametrize('N,H,Cin,Cout,K,st,act,affine,tile', CONV_CASES)
+def test_conv_forward_and_transpose(N, H, Cin, Cout, K, st, act, affine, tile):
+    pad = K // 2
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, K, K, seed=2, scale=1.0 / np.sqrt(Cin * K * K))
+    b = g(Cout, seed=3)
+    s = (torch.rand(Cin, generator=torch.Generator().manual_seed(4)) + 0.5) if affine else None
+    t = g(Cin, seed=5, scale=0.3) if affine else None
+    xr = x.clone().requires_grad_(True)
+    u = xr * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1) if affine else xr
+    ref = F.conv2d(ACTS[act](u), w, b, stride=st, padding=pad)
+    Ho = ref.shape[2]
+    y = torch.empty(N, Ho, Ho, Cout, device=DEV)
+    kw = dict(bias=b.to(DEV), pro_act=act)
+    if affine:
+        kw.update(pro_scale=s.to(DEV), pro_shift=t.to(DEV))
+    xd = nhwc(x)
+    run_conv(xd, fwd_w(w), y, K, sn=st, pad=pad, tile=tile, **kw)
+    close(nchw(y), ref, 2e-5, 'conv fwd')
+
+    # backward-to-input with the act' epilogue and an addend (= what an identity skip contributes)
+    cot = g(*ref.shape, seed=6)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    extra = g(N, Cin, H, H, seed=7)
+    dx = torch.empty(N, H, H, Cin, device=DEV)
+    kw = dict(dact_x=xd, dact_act=act, addend=nhwc(extra), ldadd=Cin, lddact=Cin)
+    if affine:
+        kw.update(dact_scale=s.to(DEV), dact_shift=t.to(DEV))
+    run_conv(nhwc(cot), bwd_w(w), dx, K, sn=1, sd=st, pad=K - 1 - pad, tile=tile, **kw)
+    close(nchw(dx), gx + extra, 2e-5, 'conv bwd')
+
+
+def test_conv_dual_source_bcast_addend_and_accumulate():
+    N, H, C1, C2, Cout = 3, 4, 16, 6, 24
+    x1, x2 = g(N, C1, H, H, seed=1), g(N, C2, H, H, seed=2)
+    w = g(Cout, C1 + C2, 1, 1, seed=3, scale=0.2)
+    add = g(1, Cout, H, H, seed=4)
+    ref = F.conv2d(torch.cat([x1, x2], 1), w) + add
+    y = torch.empty(N, H, H, Cout, device=DEV)
+    x2d = nhwc(x2)
+    run_conv(nhwc(x1), fwd_w(w), y, 1, x2=x2d, ldx2=C2, C2=C2, addend=nhwc(add), ldadd=Cout, addend_bcast_n=1)
+    close(nchw(y), ref, 2e-5, 'dual source')
+    # in-place accumulation (addend aliases y) plus second addend
+    a2 = g(N, Cout, H, H, seed=5)
+    run_conv(nhwc(x1), fwd_w(w), y, 1, x2=x2d, ldx2=C2, C2=C2, addend=y, ldadd=Cout, addend2=nhwc(a2), ldadd2=Cout)
+    close(nchw(y), ref + F.conv2d(torch.cat([x1, x2], 1), w) + a2, 2e-5, 'accumulate')
+
+
+def test_conv_per_row_prologue():
+    N, H, Cin, Cout = 4, 4, 16, 8
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, 3, 3, seed=2, scale=0.1)
+    s, t = g(N, Cin, seed=3), g(N, Cin, seed=4)
+    ref = F.conv2d(x * s.view(N, Cin, 1, 1) + t.view(N, Cin, 1, 1), w, padding=1)
+    y = torch.empty(N, H, H, Cout, device=DEV)
+    run_conv(nhwc(x), fwd_w(w), y, 3, pad=1, pro_scale=s.to(DEV), pro_shift=t.to(DEV), pro_per_row=1)
+    close(nchw(y), ref, 2e-5, 'per-row prologue')
+
+
+def test_conv_rejects_bad_descriptors():
+    d = L.ConvDesc()
+    assert L.lib.ga_conv2d(C.byref(d), None) == -1
+    with pytest.raises(L.GaError):
+        L.run(d)
+
+
+@pytest.mark.parametrize('N,H,Cc,up', [(5, 4, 48, False), (3, 8, 96, False), (2, 16, 32, False), (2, 32, 12, False),
+                                       (3, 8, 48, True), (2, 40, 8, True), (9, 4, 36, True)])
+def test_dwconv5(N, H, Cc, up):
+    hs = H // 2 if up else H
+    x = g(N, Cc, hs, hs, seed=1)
+    w = g(Cc, 1, 5, 5, seed=2, scale=0.2)
+    b = g(Cc, seed=3)
+    xr = x.clone().requires_grad_(True)
+    a = F.silu(xr)
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode='nearest')
+    ref = F.conv2d(a, w, b, padding=2, groups=Cc)
+    y = torch.empty(N, H, H, Cc, device=DEV)
+    d = L.DwDesc()
+    xd, wd, bd = nhwc(x), w.reshape(Cc, 25).t().contiguous().to(DEV), b.to(DEV)
+    d.x, d.w, d.bias, d.y = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr()
+    d.N, d.H, d.W, d.C, d.pro_act, d.up2 = N, H, H, Cc, 1, int(up)
+    L.run(d)
+    close(nchw(y), ref, 1e-5, 'dw fwd')
+
+    cot = g(*ref.shape, seed=4)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    dx = torch.empty(N, hs, hs, Cc, device=DEV)
+    b2 = L.DwDesc()
+    cd, wf = nhwc(cot), w.flip(2, 3).reshape(Cc, 25).t().contiguous().to(DEV)
+    b2.x, b2.w, b2.dact_x, b2.y = cd.data_ptr(), wf.data_ptr(), xd.data_ptr(), dx.data_ptr()
+    b2.N, b2.H, b2.W, b2.C, b2.dact_act, b2.pool2 = N, H, H, Cc, 1, int(up)
+    L.run(b2)
+    close(nchw(dx), gx, 1e-5, 'dw bwd')
+
+
+@pytest.mark.parametrize('N,H,Cc', [(3, 4, 64), (2, 8, 8), (2, 16, 132)])
+def test_se_chain(N, H, Cc):
+    """squeeze -> excite -> merge, and the backward pieces, against autograd of the same math."""
+    Hd = max(Cc // 16, 4)
+    t = g(N, Cc, H, H, seed=1)
+    skip = g(N, Cc, H, H, seed=2)
+    w1, b1, w2, b2 = g(Hd, Cc, seed=3, scale=0.3), g(Hd, seed=4), g(Cc, Hd, seed=5, scale=0.5), g(Cc, seed=6)
+    tr = t.clone().requires_grad_(True)
+    m = tr.mean(dim=[2, 3])
+    gate = torch.sigmoid(F.linear(F.relu(F.linear(m, w1, b1)), w2, b2))
+    ref = skip + 0.1 * (tr * gate.view(N, Cc, 1, 1))
+
+    td, sd_ = nhwc(t), nhwc(skip)
+    md, hid, gd = (torch.empty(N, Cc, device=DEV), torch.empty(N, Hd, device=DEV), torch.empty(N, Cc, device=DEV))
+    r = L.ReduceDesc()
+    r.a, r.out, r.N, r.P, r.C, r.scale = td.data_ptr(), md.data_ptr(), N, H * H, Cc, 1.0 / (H * H)
+    L.run(r)
+    close(md, m, 1e-6, 'squeeze')
+    W = [v.to(DEV) for v in (w1, b1, w2, b2)]
+    e = L.SeExciteDesc()
+    e.m, e.w1, e.b1, e.w2, e.b2 = md.data_ptr(), *(v.data_ptr() for v in W)
+    e.hid, e.gate, e.N, e.C, e.Hd, e.P, e.res_scale = hid.data_ptr(), gd.data_ptr(), N, Cc, Hd, H * H, 0.1
+    L.run(e)
+    close(gd, gate, 1e-6, 'gate')
+    out = torch.empty(N, H, H, Cc, device=DEV)
+    a = L.SeApplyDesc()
+    a.skip, a.t, a.gate, a.out = sd_.data_ptr(), td.data_ptr(), gd.data_ptr(), out.data_ptr()
+    a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = N, H, H, Cc, 0, 0.1
+    L.run(a)
+    close(nchw(out), ref, 1e-6, 'merge')
+
+    cot = g(N, Cc, H, H, seed=7)
+    (gt,) = torch.autograd.grad((ref * cot).sum(), [tr])
+    cd = nhwc(cot)
+    dg, ps, pb = (torch.empty(N, Cc, device=DEV) for _ in range(3))
+    r2 = L.ReduceDesc()
+    r2.a, r2.b, r2.out, r2.N, r2.P, r2.C, r2.scale = cd.data_ptr(), td.data_ptr(), dg.data_ptr(), N, H * H, Cc, 0.1
+    L.run(r2)
+    e2 = L.SeExciteDesc()
+    e2.w1, e2.b1, e2.w2, e2.b2 = (v.data_ptr() for v in W)
+    e2.hid, e2.gate, e2.dgate, e2.pro_scale, e2.pro_shift = hid.data_ptr(), gd.data_ptr(), dg.data_ptr(), ps.data_ptr(), pb.data_ptr()
+    e2.N, e2.C, e2.Hd, e2.P, e2.res_scale, e2.backward = N, Cc, Hd, H * H, 0.1, 1
+    L.run(e2)
+    torch.cuda.synchronize()
+    dt = nchw(cd) * ps.cpu().view(N, Cc, 1, 1) + pb.cpu().view(N, Cc, 1, 1)
+    close(dt, gt, 1e-6, 'se backward')
+
+
+@pytest.mark.parametrize('N,h,Cc', [(2, 4, 16), (3, 8, 8), (1, 16, 4), (2, 1, 4)])
+def test_bilinear_skip(N, h, Cc):
+    low = g(N, Cc, h, h, seed=1)
+    t = g(N, Cc, 2 * h, 2 * h, seed=2)
+    gate = torch.rand(N, Cc, generator=torch.Generator().manual_seed(3))
+    lr = low.clone().requires_grad_(True)
+    ref = F.interpolate(lr, scale_factor=2, mode='bilinear', align_corners=True) + 0.1 * t * gate.view(N, Cc, 1, 1)
+    out = torch.empty(N, 2 * h, 2 * h, Cc, device=DEV)
+    a = L.SeApplyDesc()
+    ld, td, gd = nhwc(low), nhwc(t), gate.to(DEV)
+    a.skip, a.t, a.gate, a.out = ld.data_ptr(), td.data_ptr(), gd.data_ptr(), out.data_ptr()
+    a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = N, 2 * h, 2 * h, Cc, 1, 0.1
+    L.run(a)
+    close(nchw(out), ref, 1e-6, 'bilinear fwd')
+    cot = g(*ref.shape, seed=4)
+    (gl,) = torch.autograd.grad((ref * cot).sum(), [lr])
+    dl = torch.empty(N, h, h, Cc, device=DEV)
+    b = L.BilinearBwdDesc()
+    cd = nhwc(cot)
+    b.dhigh, b.dlow, b.N, b.h, b.w, b.C, b.accumulate = cd.data_ptr(), dl.data_ptr(), N, h, h, Cc, 0
+    L.run(b)
+    close(nchw(dl), gl, 1e-6, 'bilinear bwd')
+
+
+@pytest.mark.parametrize('first', [True, False])
+def test_sampler(first):
+    N, h, NL, alpha, temp = 3, 4, 6, 0.35, 0.6
+    mq = g(N, NL, h, h, seed=1, scale=3)
+    p = None if first else g(N, 2 * NL, h, h, seed=2, scale=3)
+    eps = g(N, NL, h, h, seed=3)
+    mqr = mq.clone().requires_grad_(True)
+    pr = None if first else p.clone().requires_grad_(True)
+    sc = lambda v: torch.tanh(v / 5.0) * 5.0
+    mp, ls = (torch.zeros_like(mq), torch.zeros_like(mq)) if first else (pr[:, :NL], pr[:, NL:])
+    ref = (1 - alpha) * sc(mp + mqr) + alpha * (eps * (temp * torch.exp(sc(ls))) + sc(mp))
+    z = torch.empty(N, h, h, NL, device=DEV)
+    d = L.SamplerDesc()
+    mqd, ed = nhwc(mq), eps.to(DEV)
+    pd = None if first else nhwc(p)
+    d.mu_q, d.ldq, d.eps, d.eps_nchw, d.z = mqd.data_ptr(), NL, ed.data_ptr(), 1, z.data_ptr()
+    if not first:
+        d.p, d.ldp = pd.data_ptr(), 2 * NL
+    d.N, d.h, d.w, d.NL, d.alpha, d.one_minus_alpha, d.temp = N, h, h, NL, alpha, 1 - alpha, temp
+    L.run(d)
+    close(nchw(z), ref, 1e-6, 'sampler fwd')
+    cot = g(*ref.shape, seed=4)
+    grads = torch.autograd.grad((ref * cot).sum(), [mqr] if first else [mqr, pr])
+    dmq = torch.empty(N, h, h, NL, device=DEV)
+    dp = torch.empty(N, h, h, 2 * NL, device=DEV)
+    cd = nhwc(cot)
+    d.backward, d.dz, d.dmu_q = 1, cd.data_ptr(), dmq.data_ptr()
+    if not first:
+        d.dp = dp.data_ptr()
+    L.run(d)
+    close(nchw(dmq), grads[0], 1e-6, 'sampler dmu_q')
+    if not first:
+        close(nchw(dp), grads[1], 1e-6, 'sampler dp')
+
+
+def test_dml_mean():
+    from oracle.nvae_oracle import disc_mix_logistic_mean
+    N, H = 2, 6
+    lg = g(N, 100, H, H, seed=1, scale=1.5)
+    lr = lg.clone().requires_grad_(True)
+    ref = disc_mix_logistic_mean(lr, 10) * 0.5 + 0.5
+    ld = nhwc(lg)
+    o1, o2 = torch.empty(N, 3, H, H, device=DEV), torch.empty(N, H, H, 3, device=DEV)
+    d = L.DmlDesc()
+    d.logits, d.ld, d.nmix, d.img_nchw, d.img_nhwc, d.N, d.H, d.W = ld.data_ptr(), 100, 10, o1.data_ptr(), o2.data_ptr(), N, H, H
+    L.run(d)
+    close(o1, ref, 1e-6, 'dml nchw')
+    close(nchw(o2), ref, 1e-6, 'dml nhwc')
+    cot = g(N, 3, H, H, seed=2)
+    (gl,) = torch.autograd.grad((ref * cot).sum(), [lr])
+    dl = torch.empty(N, H, H, 100, device=DEV)
+    cd = nhwc(cot)
+    d.backward, d.dimg_nhwc, d.dlogits = 1, cd.data_ptr(), dl.data_ptr()
+    L.run(d)
+    close(nchw(dl), gl, 1e-6, 'dml bwd')
+
+
+def test_maxpool():
+    N, H, Cc = 2, 8, 12
+    x = g(N, Cc, H, H, seed=1)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = x[0, 0, 1, 0] = 5.0       # tie: first in scan order wins
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 2, 2)
+    xd = nhwc(x)
+    y = torch.empty(N, H // 2, H // 2, Cc, device=DEV)
+    d = L.MaxpoolDesc()
+    d.x, d.y, d.N, d.H, d.W, d.C = xd.data_ptr(), y.data_ptr(), N, H, H, Cc
+    L.run(d)
+    close(nchw(y), ref, 0, 'maxpool fwd')
+    cot = g(*ref.shape, seed=2)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    dx = torch.empty(N, H, H, Cc, device=DEV)
+    cd = nhwc(cot)
+    d.backward, d.dy, d.dx = 1, cd.data_ptr(), dx.data_ptr()
+    L.run(d)
+    close(nchw(dx), gx, 0, 'maxpool bwd')
+
+
+def test_image_io():
+    B, rep, H = 2, 3, 8
+    N = B * rep
+    x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(1))
+    noise = g(N, 3, H, H, seed=2)
+    coef = 2.0 / noise.flatten(1).norm(dim=1)
+    xr = x.clone().requires_grad_(True)
+    rows = xr.repeat_interleave(rep, dim=0)
+    ref = (rows + noise * coef.view(-1, 1, 1, 1)).clamp(0, 1)
+    y = torch.empty(N, H, H, 3, device=DEV)
+    d = L.ImageIoDesc()
+    xd, nd, cd = x.to(DEV), noise.to(DEV), coef.to(DEV)
+    d.x_nchw, d.noise_nchw, d.noise_coef, d.y_nhwc = xd.data_ptr(), nd.data_ptr(), cd.data_ptr(), y.data_ptr()
+    d.N, d.C, d.H, d.W, d.rep = N, 3, H, H, rep
+    L.run(d)
+    close(nchw(y), ref, 1e-7, 'image fwd')
+    cot = g(N, 3, H, H, seed=3)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    dx = torch.empty(B, 3, H, H, device=DEV)
+    ct = nhwc(cot)
+    d.backward, d.dy_nhwc, d.dx_nchw = 1, ct.data_ptr(), dx.data_ptr()
+    L.run(d)
+    close(dx, gx, 1e-6, 'image bwd')
+
+
+def test_plan_replay_matches_direct_calls():
+    N, H, Cin, Cout = 2, 8, 16, 16
+    x = nhwc(g(N, Cin, H, H, seed=1))
+    w = fwd_w(g(Cout, Cin, 3, 3, seed=2, scale=0.1))
+    y1 = torch.empty(N, H, H, Cout, device=DEV)
+    y2 = torch.empty(N, H, H, Cout, device=DEV)
+    d = run_conv(x, w, y1, 3, pad=1)
+    d2 = L.ConvDesc.from_buffer_copy(d)
+    d2.y = y2.data_ptr()
+    p = L.Plan()
+    p.add(d2, 'conv')
+    ax = L.AxpbyDesc()
+    ax.x, ax.y, ax.n, ax.alpha, ax.beta = y1.data_ptr(), y2.data_ptr(), y1.numel(), -1.0, 1.0
+    p.add(ax, 'diff')
+    p.run(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert y2.abs().max().item() == 0.0
+    ms, conv_ms, nconv = p.time(torch.cuda.current_stream().cuda_stream, iters=2, per_conv=True)
+    assert ms > 0 and nconv == 1 and conv_ms > 0
