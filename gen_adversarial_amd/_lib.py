@@ -191,13 +191,18 @@ class Plan:
     def __len__(self):
         return len(self.descs)
 
-    def run(self, stream: int = 0):
+    def run(self, stream: int = 0, start: int = 0, end: int = None):
+        """Replay ops[start:end) with one C call."""
         if self._arr is None:
             self.finalize()
+        end = len(self.descs) if end is None else end
+        if end <= start:
+            return
         failed = C.c_int(-1)
-        rc = lib.ga_plan_run(self._arr, len(self.descs), stream, C.byref(failed))
+        first = C.cast(C.byref(self._arr, start * C.sizeof(Op)), C.POINTER(Op))
+        rc = lib.ga_plan_run(first, end - start, stream, C.byref(failed))
         if rc != 0:
-            check(rc, f'plan op #{failed.value} ({self.names[failed.value]})')
+            check(rc, f'plan op #{start + failed.value} ({self.names[start + failed.value]})')
 
     def time(self, stream: int = 0, iters: int = 1, per_conv: bool = False):
         if self._arr is None:

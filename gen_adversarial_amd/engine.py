@@ -379,22 +379,30 @@ class Engine:
         dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
         dm.N, dm.H, dm.W, dm.backward = R, H, H, 0
         self.fwd.add(dm, 'dml_mean')
-        self.dpurified = None    # optional external gradient on the purified image (NCHW), set by the caller
+        self.dpurified = self.alloc((R, 3, H, H))    # optional external gradient on the purified image (NCHW)
+        purified_img = img
 
         def bwd_dml():
             b = L.DmlDesc()
             b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
+            b.dimg_nchw = _ptr(self.dpurified)
             b.N, b.H, b.W, b.backward = R, H, H, 1
             self.bwd.add(b, 'dml_mean^T')
             self.grad_conv('to_logits^T', logits.g, tl['w_bwd'], post_out, K=3, pad=1, dact_x=post_out.t, dact_act=L.GA_ACT_ELU)
         self._bwd_steps.append(bwd_dml)
 
         # ---- classifier
+        n_nvae_steps = len(self._bwd_steps)
         self.logits = self._build_vgg(vgg_sd, img)
+        self._purified_grad_nhwc = purified_img
 
-        # ---- emit the backward plan: reverse registration order
+        # ---- emit the backward plan: reverse registration order (classifier part first)
+        self.bwd_split = 0
         if self.need_backward:
-            for step in reversed(self._bwd_steps):
+            for step in reversed(self._bwd_steps[n_nvae_steps:]):
+                step()
+            self.bwd_split = len(self.bwd)
+            for step in reversed(self._bwd_steps[:n_nvae_steps]):
                 step()
         self.fwd.finalize()
         self.bwd.finalize()
@@ -541,9 +549,17 @@ class Engine:
             raise RuntimeError('dry-run engine: plans were built for validation only')
         self.fwd.run(self.stream())
 
-    def backward(self):
+    def backward(self, from_logits: bool = True, from_purified: bool = False):
+        """Backward-to-input of the last forward.  Cotangents are read from `self.dlogits` (rows x classes) when
+        from_logits and from `self.dpurified` (NCHW) when from_purified.  May be called repeatedly per forward."""
         if not self.need_backward:
             raise RuntimeError('engine was built without a backward plan')
         if self.dry_run:
             raise RuntimeError('dry-run engine: plans were built for validation only')
-        self.bwd.run(self.stream())
+        if not from_purified:
+            self.dpurified.zero_()
+        if from_logits:
+            self.bwd.run(self.stream())
+        else:
+            self._purified_grad_nhwc.g.zero_()
+            self.bwd.run(self.stream(), start=self.bwd_split)

@@ -1,0 +1,99 @@
+"""Debug helper (GPU): compares engine gradients of cell outputs against oracle autograd."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+from gen_adversarial_amd.engine import Engine
+from gen_adversarial_amd.nvae_spec import init_nvae_state_dict, build_spec
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
+from oracle import nvae_oracle as O, defender_oracle as D
+
+cfg = {'initial_channels': 16, 'num_pre-post_process_blocks': 2, 'num_pre-post_process_cells': 2, 'num_scales': 3,
+       'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 2,
+       'num_latent_per_group': 20, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+res = (3, 64, 64)
+spec = build_spec(cfg, res)
+sd = init_nvae_state_dict(cfg, res, 3)
+vspec = build_vgg_spec(100, 8); vsd = init_vgg_state_dict(100, 8, 4)
+rows, rep = 8, 4
+alphas = [0.7 * i / (len(spec.groups) - 1) for i in range(len(spec.groups))]
+gen = torch.Generator().manual_seed(0)
+imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+eps = [torch.randn(rows, 20, gs.res, gs.res, generator=gen) for gs in spec.groups]
+noise = torch.randn(rows, 3, 64, 64, generator=gen)
+
+rec = {}
+_enc, _dec = O.enc_cell, O.dec_cell
+def enc(sd_, cell, x_):
+    y = _enc(sd_, cell, x_); y.retain_grad(); rec[cell.prefix + '.out'] = y; return y
+def dec(sd_, cell, x_):
+    y = _dec(sd_, cell, x_); y.retain_grad(); rec[cell.prefix + '.out'] = y; return y
+O.enc_cell, O.dec_cell = enc, dec
+_vf = D.vgg_forward
+xr = imgs.clone().requires_grad_(True)
+logits, purified = D.nvae_defender(sd, spec, vsd, vspec, xr.repeat_interleave(rep, dim=0), alphas, eps, noise, 0.0)
+purified.retain_grad()
+cot = torch.randn(logits.shape, generator=gen)
+(logits * cot).sum().backward()
+
+eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device='cuda:0')
+eng.x_in.copy_(imgs.cuda())
+for b, e in zip(eng.eps, eps): b.copy_(e.cuda())
+eng.forward()
+eng.dlogits.view_as(eng.logits).copy_(cot.cuda())
+eng.backward(); torch.cuda.synchronize()
+print('purified grad', (eng.acts['purified_nhwc'].g.permute(0,3,1,2).cpu() - purified.grad).abs().max().item(), purified.grad.abs().max().item())
+for k in reversed(list(eng.acts.keys())):
+    a = eng.acts[k]
+    if k in rec and a._g is not None:
+        r = rec[k].grad
+        e = (a.g.permute(0, 3, 1, 2).cpu() - r).abs().max().item()
+        print(f'{k:60s} gerr {e:.3e}  ref max {r.abs().max():.3e}')
+print('dx err', (eng.dx.cpu() - xr.grad).abs().max().item(), xr.grad.abs().max().item())
+
+# ---- VGG internals
+import torch.nn.functional as F
+x = eng.purified.cpu().clone().requires_grad_(True)
+h = (x - 0.5) / 0.5
+recv = {}
+for op in vspec.program:
+    if op[0] == 'pool':
+        h = F.max_pool2d(h, 2, 2)
+        h.retain_grad(); recv[last + '.pool'] = h
+    else:
+        _, i, _, _ = op
+        h = F.conv2d(h, vsd[f'model.features.{i}.weight'], vsd[f'model.features.{i}.bias'], padding=1)
+        b = f'model.features.{i + 1}'
+        h = F.batch_norm(h, vsd[f'{b}.running_mean'], vsd[f'{b}.running_var'], vsd[f'{b}.weight'], vsd[f'{b}.bias'], False, 0.0, 1e-5)
+        h.retain_grad(); recv[f'vgg.conv{i}'] = h; last = f'vgg.conv{i}'
+        h = F.relu(h)
+feat = h; 
+h = F.adaptive_avg_pool2d(h, (7, 7)).flatten(1)
+h = F.linear(h, vsd['model.classifier.0.weight'])
+c = 'model.classifier.1'
+h = F.batch_norm(h, vsd[f'{c}.running_mean'], vsd[f'{c}.running_var'], vsd[f'{c}.weight'], vsd[f'{c}.bias'], False, 0.0, 1e-5)
+h.retain_grad(); recv['vgg.head1'] = h
+h = F.relu(h)
+out = F.linear(h, vsd['model.classifier.3.weight'], vsd['model.classifier.3.bias'])
+(out * cot).sum().backward()
+print('vgg logits err', (out - eng.logits.cpu()).abs().max().item())
+for k in reversed(list(recv.keys())):
+    a = eng.acts[k]; r = recv[k].grad
+    ag = a.g.permute(0, 3, 1, 2).cpu().reshape(r.shape)
+    print(f'{k:30s} gerr {(ag - r).abs().max().item():.3e} ref max {r.abs().max():.3e}')
+print('x grad err', (eng.acts['purified_nhwc'].g.permute(0,3,1,2).cpu() - x.grad).abs().max().item())
+
+for k in ('vgg.conv0', 'vgg.conv4', 'vgg.conv11'):
+    t = eng.acts[k].t.permute(0, 3, 1, 2).cpu()
+    n, c, hh, ww = t.shape
+    w4 = t.reshape(n, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, hh // 2, ww // 2, 4)
+    mx = w4.max(dim=-1, keepdim=True).values
+    ties = ((w4 == mx).sum(-1) > 1) & (mx[..., 0] > 0)
+    tr = recv[k].detach()
+    w4r = tr.reshape(n, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, hh // 2, ww // 2, 4)
+    mxr = w4r.max(dim=-1, keepdim=True).values
+    tiesr = ((w4r == mxr).sum(-1) > 1) & (mxr[..., 0] > 0)
+    print(k, 'positive ties: engine', ties.sum().item(), 'cpu ref', tiesr.sum().item(), 'of', ties.numel(),
+          'argmax differs', (w4.argmax(-1) != w4r.argmax(-1)).sum().item())
+p = eng.purified.cpu()
+print('purified saturated fraction', ((p == 0) | (p == 1)).float().mean().item())

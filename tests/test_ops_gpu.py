@@ -88,6 +88,9 @@ CONV_CASES = [
     (1, 32, 8, 16, 3, 2, 0, False, 4),
     (1, 16, 8, 16, 3, 2, 0, False, 4),
     (1, 16, 32, 16, 3, 2, 0, False, 4),
+    (8, 16, 16, 32, 3, 1, 3, False, 0),
+    (8, 32, 8, 16, 3, 1, 3, False, 0),
+    (8, 64, 3, 8, 3, 1, 0, True, 0),
 ]
 
 
@@ -317,8 +320,8 @@ def test_dml_mean():
     close(nchw(dl), gl, 1e-6, 'dml bwd')
 
 
-def test_maxpool():
-    N, H, Cc = 2, 8, 12
+@pytest.mark.parametrize('N,H,Cc', [(2, 8, 12), (8, 32, 16), (8, 64, 8), (3, 16, 32)])
+def test_maxpool(N, H, Cc):
     x = g(N, Cc, H, H, seed=1)
     x[0, 0, 0, 0] = x[0, 0, 0, 1] = x[0, 0, 1, 0] = 5.0       # tie: first in scan order wins
     xr = x.clone().requires_grad_(True)
