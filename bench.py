@@ -1,0 +1,204 @@
+"""
+bench.py — purification-under-attack throughput on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+One "step" = one white-box attack iteration over one batch of defender rows:
+  EoT repeat -> NVAE purify (encode + decode) -> VGG-11 classify -> EoT-mean logits -> CE loss
+  -> backward-to-input through classifier and purifier -> PGD-Linf sign step + projection,
+with fresh N(0,1) latent noise every step, synthetic images already resident in HBM.
+Workload at N=1: BASELINE.json configs[1] — NVAE purify, CelebA-64 shapes, 256 rows (8 images x EoT 32), fp32,
+alphas of configs/ours_cosine_no_preprocessing_ids.yaml x 0.7, assumed NVAE config of SURVEY.md §6.
+N>1: the same batch per rank (weak scaling, images are independent), one RCCL all-gather of accuracy counters.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def conv_algorithmic_flops(plan):
+    """2 * MACs of every ga_conv2d launch in a plan (dense taps; transposed convs counted at their forward size)."""
+    from gen_adversarial_amd import _lib as L
+    total = 0
+    for d in plan.descs:
+        if isinstance(d, L.ConvDesc):
+            ctot = d.C1 + d.C2
+            pix = d.N * d.Ho * d.Wo if d.sd == 1 else d.N * d.Hi * d.Wi
+            total += 2 * pix * d.KH * d.KW * ctot * d.Cout
+    return total
+
+
+def build_model(device, rows, rep, seed=0):
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, init_nvae_state_dict
+    from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
+    with open(os.path.join(ROOT, 'configs', 'ours_cosine_no_preprocessing_ids.yaml')) as f:
+        y = yaml.safe_load(f)
+    alphas = [a * y['alpha_attenuation'] for a in y['interpolation_alphas']]
+    sd = init_nvae_state_dict(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, seed)
+    vspec = build_vgg_spec(100, 1)
+    vsd = init_vgg_state_dict(100, 1, seed + 1)
+    eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=rows, rep=rep, alphas=alphas,
+                 temperature=0.6, noise_eps=float(y['initial_noise_eps']), device=device)
+    return eng, (sd, vsd, vspec, alphas)
+
+
+class AttackStep:
+    """PGD-Linf iteration on the engine (eps 8/255, step 2/255)."""
+
+    def __init__(self, eng, labels, x_orig, eps=8.0 / 255.0, step=2.0 / 255.0):
+        self.eng, self.labels, self.x_orig, self.eps, self.step_size = eng, labels, x_orig, eps, step
+        self.x_adv = x_orig.clone()
+        self.rep = eng.rep
+
+    def __call__(self):
+        eng = self.eng
+        eng.x_in.copy_(self.x_adv)
+        for e in eng.eps:
+            e.normal_()
+        eng.forward()
+        logits = eng.logits.view(-1, self.rep, eng.logits.shape[-1]).mean(dim=1)          # EoT mean
+        p = torch.softmax(logits, dim=1)
+        p[torch.arange(p.shape[0], device=p.device), self.labels] -= 1.0                   # d CE / d mean-logits
+        eng.dlogits.view(-1, self.rep, p.shape[-1]).copy_((p / self.rep).unsqueeze(1).expand(-1, self.rep, -1))
+        eng.backward()
+        nxt = self.x_adv + self.step_size * eng.dx.sign()
+        self.x_adv = torch.min(torch.max(nxt, self.x_orig - self.eps), self.x_orig + self.eps).clamp_(0.0, 1.0)
+        return logits
+
+
+def cpu_baseline(model, rows, rep):
+    """the oracle (CPU restatement) on the host cores: one attack step (forward + input-gradient) on `rows` rows."""
+    from oracle import defender_oracle as D
+    from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, build_spec
+    sd, vsd, vspec, alphas = model
+    spec = build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION)
+    cores = os.cpu_count() or 1
+    threads = min(cores, int(os.environ.get('GA_CPU_THREADS', cores)))
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(rows // rep, 3, 64, 64, generator=g).requires_grad_(True)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=g) for gs in spec.groups]
+    noise = torch.randn(rows, 3, 64, 64, generator=g)
+    t0 = time.time()
+    logits, _ = D.nvae_defender(sd, spec, vsd, vspec, x.repeat_interleave(rep, dim=0), alphas, eps, noise, 0.0)
+    mean = logits.view(-1, rep, logits.shape[-1]).mean(dim=1)
+    loss = torch.nn.functional.cross_entropy(mean, mean.argmax(dim=1).detach(), reduction='sum')
+    torch.autograd.grad(loss, [x])
+    dt = time.time() - t0
+    return {'value': rows / dt, 'unit': 'rows/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{rows // rep} image(s) x EoT {rep} = {rows} rows, one attack step (forward + input-gradient), '
+                      f'{dt:.1f} s; autograd also forms weight gradients as the reference does'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--rows', type=int, default=256)
+    ap.add_argument('--eot', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    device = f'cuda:{local_rank}'
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+
+    eng, model = build_model(device, args.rows, args.eot, seed=0)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    x = torch.rand(args.rows // args.eot, 3, 64, 64, device=device, generator=g)
+    # labels = clean prediction of the defender, so that the attack starts from "correct" 
+    eng.x_in.copy_(x)
+    for e in eng.eps:
+        e.normal_()
+    eng.forward()
+    labels = eng.logits.view(-1, args.eot, eng.logits.shape[-1]).mean(dim=1).argmax(dim=1)
+    step = AttackStep(eng, labels, x)
+
+    for _ in range(args.warmup):
+        step()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    # the path's only collective: accuracy counters of every rank (reference: test_defense.py:240-248)
+    correct = (logits.argmax(dim=1) == labels).sum().view(1).float()
+    counters = torch.stack([correct.squeeze(0), torch.tensor(float(labels.numel()), device=device)])
+    if dist is not None:
+        gathered = [torch.zeros_like(counters) for _ in range(world)]
+        dist.all_gather(gathered, counters)
+        counters = torch.stack(gathered).sum(dim=0)
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        rows_total = args.rows * world * args.steps
+        # ---- roofline of the dominant kernel (conv_mfma_kernel): HIP events on the plan's stream, per launch
+        s = eng.stream()
+        f_ms, fc_ms, fn = eng.fwd.time(s, iters=1, per_conv=True)
+        b_ms, bc_ms, bn = eng.bwd.time(s, iters=1, per_conv=True)
+        flops = conv_algorithmic_flops(eng.fwd) + conv_algorithmic_flops(eng.bwd)
+        conv_s = (fc_ms + bc_ms) / 1e3
+        achieved = flops / conv_s / 1e12
+        out = {
+            'metric': 'purified images/sec (attack+encode+decode)',
+            'value': rows_total / dt,
+            'unit': 'defender rows/s (rows = images x EoT-32)',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: NVAE purify + VGG-11, 64x64, PGD-Linf step (fwd + input-grad), '
+                                   f'{args.rows} rows/GPU = {args.rows // args.eot} images x EoT {args.eot}, '
+                                   'alphas ours_cosine_no_preprocessing_ids.yaml x0.7, assumed NVAE config (C=32, 3x8 groups, 20 latents)',
+                       'rows_per_gpu': args.rows, 'eot': args.eot, 'images_per_step': args.rows // args.eot * world,
+                       'parallelism': f'image-sharded x{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'ga::conv_mfma_kernel (fp32 implicit-GEMM conv, all instantiations)',
+                         'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'launches_per_step': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                         'algorithmic_gflop_per_step': flops / 1e9,
+                         'conv_ms_per_step': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms},
+            'accuracy_counters': [float(counters[0].item()), float(counters[1].item())],
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                out['cpu_baseline'] = cpu_baseline(model, args.eot, args.eot)
+            except Exception as ex:   # the baseline is a reported number, never a reason to lose the bench line
+                out['cpu_baseline'] = {'value': None, 'unit': 'rows/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {ex}'}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,85 @@
+"""
+Checkpoint ingestion with the reference's file layouts (src/defenses/loading_utils.py:10-81), returning plain weight
+holders instead of nn.Modules: the arithmetic lives in libga_ops, not in torch modules.
+
+  load_Vgg11(path, device, n_classes=100)   ckpt['state_dict'] with keys model.features.N.*, model.classifier.{0,1,3}.*
+  load_NVAE(path, device, temperature)      ckpt['configuration'] {'autoencoder': cfg, 'resolution': (C,H,W)} and
+                                            ckpt[f'state_dict_temp={temperature}']
+E4E / Style-Transformer / ResNet loaders are the "next" rows of SURVEY.md §8 and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Tuple
+
+import torch
+
+from ..nvae_spec import build_spec
+from ..vgg_spec import build_vgg_spec
+
+
+@dataclass
+class VggWeights:
+    state_dict: Dict[str, torch.Tensor]
+    n_classes: int
+    width_div: int = 1
+
+    @property
+    def spec(self):
+        return build_vgg_spec(self.n_classes, self.width_div)
+
+    def to(self, device):          # nn.Module-like no-ops so that caller code written for the reference keeps working
+        return self
+
+    def eval(self):
+        return self
+
+
+@dataclass
+class NVAEWeights:
+    state_dict: Dict[str, torch.Tensor]
+    config: dict
+    resolution: Tuple[int, int, int]
+
+    @property
+    def spec(self):
+        return build_spec(self.config, self.resolution)
+
+    @property
+    def num_scales(self):
+        return self.config['num_scales']
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+
+def _torch_load(path):
+    return torch.load(path, map_location='cpu', weights_only=False)
+
+
+def load_Vgg11(path: str, device: str, n_classes: int = 100) -> VggWeights:
+    ckpt = _torch_load(path)
+    sd = ckpt['state_dict']
+    width_div = 64 // sd['model.features.0.weight'].shape[0]
+    return VggWeights(sd, sd['model.classifier.3.weight'].shape[0] if n_classes is None else n_classes, width_div)
+
+
+def load_NVAE(checkpoint_path: str, device: str, temperature: float) -> NVAEWeights:
+    ckpt = _torch_load(checkpoint_path)
+    config = ckpt['configuration']
+    return NVAEWeights(ckpt[f'state_dict_temp={temperature}'], dict(config['autoencoder']), tuple(config['resolution']))
+
+
+def _next(name):
+    def fn(*a, **k):
+        raise NotImplementedError(f'{name}: not on the built path yet (SURVEY.md §8 rows a13-a18 are "next")')
+    return fn
+
+
+load_ResNet50 = _next('load_ResNet50')
+load_ResNext50 = _next('load_ResNext50')
+load_E4EStyleGan = _next('load_E4EStyleGan')
+load_TranStyleGan = _next('load_TranStyleGan')

@@ -29,6 +29,22 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+class WeightStore:
+    """Folded weights on the device, shared by every engine (row count) built for one model."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cache: Dict[str, dict] = {}
+        self.bytes = 0
+
+    def get(self, key: str, fn):
+        if key not in self.cache:
+            d = {k: v.to(self.device, dtype=torch.float32).contiguous() for k, v in fn().items()}
+            self.bytes += sum(v.numel() * 4 for v in d.values())
+            self.cache[key] = d
+        return self.cache[key]
+
+
 class Act:
     """An NHWC activation buffer plus its (lazily allocated) gradient buffer."""
 
@@ -49,7 +65,8 @@ class Act:
 class Engine:
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
-                 device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False):
+                 device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
+                 store: Optional[WeightStore] = None):
         if rows % rep:
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.device = torch.device(device)
@@ -57,17 +74,22 @@ class Engine:
         if self.device.type != 'cuda' and not dry_run:
             raise RuntimeError('the HIP engine needs a GPU device; there is no CPU fallback '
                                '(dry_run=True only builds and validates the plans)')
-        self.spec: NVAESpec = build_spec(nvae_cfg, resolution)
+        self.store = store if store is not None else WeightStore(self.device)
+        self.has_nvae = nvae_sd is not None
+        self.spec: Optional[NVAESpec] = build_spec(nvae_cfg, resolution) if self.has_nvae else None
+        self.resolution = tuple(resolution)
         self.vspec = vgg_spec
         self.rows, self.rep = rows, rep
         self.alphas = [float(a) for a in alphas]
-        if len(self.alphas) != len(self.spec.groups):
+        if self.has_nvae and len(self.alphas) != len(self.spec.groups):
             raise ValueError(f'{len(self.spec.groups)} interpolation alphas expected, got {len(self.alphas)}')
         self.temperature = float(temperature)
         self.noise_eps = float(noise_eps)
         self.need_backward = need_backward
         self.bytes = 0
         self.acts = {}                       # name -> Act (debugging / tests)
+        self.version = 0                     # bumped by callers after each forward (stale-backward detection)
+        self._sampler_descs = []             # (desc, latent index): alphas can be changed without rebuilding
         self._keep = []                      # weights etc.
         self.fwd = L.Plan()
         self.bwd = L.Plan()
@@ -87,8 +109,9 @@ class Engine:
         self.bytes += t.numel() * 4
         return t
 
-    def devd(self, d: dict) -> dict:
-        return {k: self.dev(v) for k, v in d.items()}
+    def devd(self, key: str, fn) -> dict:
+        """folded weights by key, computed + uploaded once per model (WeightStore)."""
+        return self.store.get(key, fn)
 
     # ------------------------------------------------------------------------------------------------ op emitters
     def conv(self, plan, name, x, w, y, *, cin=None, cout=None, bias=None, K=1, sn=1, sd=1, pad=0,
@@ -179,7 +202,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ cells
     def enc_cell(self, cell: EncCellSpec, x: Act) -> Act:
         """ResidualCellEncoder (architecture.py:96-136): fwd ops now, bwd ops registered for later."""
-        wts = self.devd(F.fold_enc_cell(self.nvae_sd, cell))
+        wts = self.devd(cell.prefix, lambda: F.fold_enc_cell(self.nvae_sd, cell))
         n, h, w = x.n, x.h, x.w
         st = 2 if cell.down else 1
         ho, wo = h // st, w // st
@@ -219,7 +242,7 @@ class Engine:
     def dec_cell(self, cell: DecCellSpec, x: Act) -> Act:
         """ResidualCellDecoder (architecture.py:139-186) with nearest-up folded into the depthwise read and the
         SkipUp 1x1 applied before its bilinear interpolation."""
-        wts = self.devd(F.fold_dec_cell(self.nvae_sd, cell))
+        wts = self.devd(cell.prefix, lambda: F.fold_dec_cell(self.nvae_sd, cell))
         n, h, w = x.n, x.h, x.w
         up = cell.up
         H, W = (2 * h, 2 * w) if up else (h, w)
@@ -271,18 +294,15 @@ class Engine:
     def _build(self, nvae_sd, vgg_sd):
         self.nvae_sd = nvae_sd
         self._scratch = {}
-        spec, R = self.spec, self.rows
-        H = spec.resolution
-        NL = spec.num_latent
-        dev = self.device
+        R = self.rows
+        H = self.resolution[1]
 
         # ---- boundary buffers (caller-visible)
         self.x_in = self.alloc((R // self.rep, 3, H, H))                    # NCHW images in [0,1]
         self.noise = self.alloc((R, 3, H, H)) if self.noise_eps != 0.0 else None
         self.noise_coef = self.alloc((R,)) if self.noise_eps != 0.0 else None
-        self.eps = [self.alloc((R, NL, gs.res, gs.res)) for gs in spec.groups]   # NCHW like the reference draws them
-        self.purified = self.alloc((R, 3, H, H))                            # NCHW
         self.dx = self.alloc((R // self.rep, 3, H, H))
+        self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
 
         x0 = Act(self, R, H, H, 3, 'x0')
         io = L.ImageIoDesc()
@@ -298,10 +318,37 @@ class Engine:
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
+        img = self._build_nvae(x0) if self.has_nvae else x0
+
+        # ---- classifier
+        n_nvae_steps = len(self._bwd_steps)
+        self.logits = self._build_vgg(vgg_sd, img)
+
+        # ---- emit the backward plan: reverse registration order (classifier part first)
+        self.bwd_split = 0
+        if self.need_backward:
+            for step in reversed(self._bwd_steps[n_nvae_steps:]):
+                step()
+            self.bwd_split = len(self.bwd)
+            for step in reversed(self._bwd_steps[:n_nvae_steps]):
+                step()
+        self.fwd.finalize()
+        self.bwd.finalize()
+        self._bwd_steps = None
+
+    def _build_nvae(self, x0: Act) -> Act:
+        """NVAEDefenseModel.purify (models.py:160-274) on the NHWC image x0; returns the purified NHWC image."""
+        nvae_sd = self.nvae_sd
+        spec, R = self.spec, self.rows
+        H = spec.resolution
+        NL = spec.num_latent
+        self.eps = [self.alloc((R, NL, gs.res, gs.res)) for gs in spec.groups]   # NCHW like the reference draws them
+        self.purified = self.alloc((R, 3, H, H))                            # NCHW
+
         # ---- stem: normalisation (x-0.5)/0.5 as prologue affine, then weight-normed 3x3 (model.py:106-107)
-        stem = self.devd(F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'))
-        two = self.dev(torch.full((3,), 2.0))
-        mone = self.dev(torch.full((3,), -1.0))
+        stem = self.devd('stem', lambda: F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'))
+        norm = self.devd('norm05', lambda: {'two': torch.full((3,), 2.0), 'mone': torch.full((3,), -1.0)})
+        two, mone = norm['two'], norm['mone']
         x = Act(self, R, H, H, spec.base_channels, 'stem')
         self.conv(self.fwd, 'stem', x0.t, stem['w'], x.t, bias=stem['b'], K=3, pad=1, pro_scale=two, pro_shift=mone)
         stem_out = x
@@ -326,23 +373,24 @@ class Engine:
         #      dist_enc.mu alone, models.py:199-206)
         C0 = spec.enc0_channels
         g0 = spec.groups[0]
-        enc0 = self.devd(F.fold_wn_conv(nvae_sd, 'encoder_0.1'))
+        enc0 = self.devd('encoder_0', lambda: F.fold_wn_conv(nvae_sd, 'encoder_0.1'))
         e0 = Act(self, R, g0.res, g0.res, C0, 'enc0')
         self.conv(self.fwd, 'encoder_0', x_top.t, enc0['w'], e0.t, bias=enc0['b'], K=1, pro_act=L.GA_ACT_ELU)
-        s00 = self.devd(F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)))
+        s00 = self.devd('enc_sampler_0:0', lambda: F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)))
         muq0 = Act(self, R, g0.res, g0.res, NL, 'mu_q0')
         self.conv(self.fwd, 'enc_sampler_0:0', e0.t, s00['w'], muq0.t, bias=s00['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
         z = Act(self, R, g0.res, g0.res, NL, 'z0')
         self._sampler_fwd('sample_0:0', muq0, None, self.eps[0], z, self.alphas[0])
 
         # ---- combiner_0:0 on cat[const_prior, z0]: the prior half is row-independent -> folded into a broadcast addend
-        comb = F.fold_wn_conv(nvae_sd, 'decoder_combiners.combiner_0:0.conv')
-        wfull = F.wn_weight64(nvae_sd, 'decoder_combiners.combiner_0:0.conv')[:, :, 0, 0]       # [C0, C0+NL]
-        prior = nvae_sd['const_prior'].double()[0]                                               # [C0,h,w]
-        pc = torch.einsum('oc,chw->hwo', wfull[:, :C0], prior) + nvae_sd['decoder_combiners.combiner_0:0.conv.bias'].double()
-        pc = self.dev(pc.float().unsqueeze(0))                                                   # [1,h,w,C0]
-        wz = self.dev(wfull[:, C0:].float())
-        wz_bwd = self.dev(wfull[:, C0:].t().float())
+        def fold_comb0():
+            wfull = F.wn_weight64(nvae_sd, 'decoder_combiners.combiner_0:0.conv')[:, :, 0, 0]   # [C0, C0+NL]
+            prior = nvae_sd['const_prior'].double()[0]                                           # [C0,h,w]
+            pc = torch.einsum('oc,chw->hwo', wfull[:, :C0], prior) + \
+                nvae_sd['decoder_combiners.combiner_0:0.conv.bias'].double()
+            return {'pc': pc.float().unsqueeze(0), 'wz': wfull[:, C0:].float(), 'wz_bwd': wfull[:, C0:].t().float()}
+        c0w = self.devd('combiner_0:0', fold_comb0)
+        pc, wz, wz_bwd = c0w['pc'], c0w['wz'], c0w['wz_bwd']                                     # pc: [1,h,w,C0]
         x = Act(self, R, g0.res, g0.res, C0, 'comb_0:0')
         self.conv(self.fwd, 'combiner_0:0', z.t, wz, x.t, K=1, addend=pc, addend_bcast=True)
         comb0_out, z0 = x, z
@@ -370,7 +418,7 @@ class Engine:
             x = self.dec_cell(cell, x)
 
         # ---- to_logits (ELU -> 3x3, model.py:310-313) + DiscMixLogistic.mean + denormalise
-        tl = self.devd(F.fold_wn_conv(nvae_sd, 'to_logits.1'))
+        tl = self.devd('to_logits', lambda: F.fold_wn_conv(nvae_sd, 'to_logits.1'))
         logits = Act(self, R, H, H, spec.logits_out, 'mix_logits')
         post_out = x
         self.conv(self.fwd, 'to_logits', x.t, tl['w'], logits.t, bias=tl['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
@@ -391,22 +439,8 @@ class Engine:
             self.grad_conv('to_logits^T', logits.g, tl['w_bwd'], post_out, K=3, pad=1, dact_x=post_out.t, dact_act=L.GA_ACT_ELU)
         self._bwd_steps.append(bwd_dml)
 
-        # ---- classifier
-        n_nvae_steps = len(self._bwd_steps)
-        self.logits = self._build_vgg(vgg_sd, img)
         self._purified_grad_nhwc = purified_img
-
-        # ---- emit the backward plan: reverse registration order (classifier part first)
-        self.bwd_split = 0
-        if self.need_backward:
-            for step in reversed(self._bwd_steps[n_nvae_steps:]):
-                step()
-            self.bwd_split = len(self.bwd)
-            for step in reversed(self._bwd_steps[:n_nvae_steps]):
-                step()
-        self.fwd.finalize()
-        self.bwd.finalize()
-        self._bwd_steps = None
+        return img
 
     # ------------------------------------------------------------------------------------------------ latents
     def _sampler_fwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float):
@@ -417,6 +451,7 @@ class Engine:
         d.eps, d.eps_nchw, d.z = _ptr(eps), 1, _ptr(z.t)
         d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 0
+        self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.fwd.add(d, name)
 
     def _sampler_bwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float, dp: Optional[Act]):
@@ -429,20 +464,23 @@ class Engine:
         muq.g_written = True
         d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 1
+        self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.bwd.add(d, name)
 
     def _latent_group(self, gs, x: Act, enc_feat: Act) -> Act:
         """models.py:236-257 for one latent group: encoder/decoder parameters, interpolation, combiner."""
         sd, R, NL, C, r = self.nvae_sd, self.rows, self.spec.num_latent, gs.channels, gs.res
         key = f'{gs.s}:{gs.g}'
-        ec_w = self.devd(F.fold_wn_conv(sd, f'encoder_combiners.combiner_{key}.conv'))
-        es_w = self.devd(F.fold_wn_conv(sd, f'enc_sampler.sampler_{key}', out_slice=slice(0, NL)))
-        ds_w = self.devd(F.fold_wn_conv(sd, f'dec_sampler.sampler_{key}.1'))
-        cb = F.wn_weight64(sd, f'decoder_combiners.combiner_{key}.conv')[:, :, 0, 0]             # [C, C+NL]
-        cb_w = self.dev(cb.float())
-        cb_b = self.dev(sd[f'decoder_combiners.combiner_{key}.conv.bias'])
-        cbx_bwd = self.dev(cb[:, :C].t().float())
-        cbz_bwd = self.dev(cb[:, C:].t().float())
+        ec_w = self.devd(f'enc_combiner_{key}', lambda: F.fold_wn_conv(sd, f'encoder_combiners.combiner_{key}.conv'))
+        es_w = self.devd(f'enc_sampler_{key}', lambda: F.fold_wn_conv(sd, f'enc_sampler.sampler_{key}', out_slice=slice(0, NL)))
+        ds_w = self.devd(f'dec_sampler_{key}', lambda: F.fold_wn_conv(sd, f'dec_sampler.sampler_{key}.1'))
+
+        def fold_comb():
+            cb = F.wn_weight64(sd, f'decoder_combiners.combiner_{key}.conv')[:, :, 0, 0]         # [C, C+NL]
+            return {'w': cb.float(), 'b': sd[f'decoder_combiners.combiner_{key}.conv.bias'],
+                    'x_bwd': cb[:, :C].t().float(), 'z_bwd': cb[:, C:].t().float()}
+        cbw = self.devd(f'combiner_{key}', fold_comb)
+        cb_w, cb_b, cbx_bwd, cbz_bwd = cbw['w'], cbw['b'], cbw['x_bwd'], cbw['z_bwd']
         alpha = self.alphas[gs.latent_idx]
         eps = self.eps[gs.latent_idx]
 
@@ -481,14 +519,14 @@ class Engine:
         """Vgg.forward on the purified image (abstract_models.py:188 -> :53-62): normalise (0.5,0.5) as prologue affine,
         conv+BN folded, ReLU as the next op's prologue, max-pool on pre-activations."""
         vs, R = self.vspec, self.rows
-        two = self.dev(torch.full((3,), 2.0))
-        mone = self.dev(torch.full((3,), -1.0))
+        norm = self.devd('norm05', lambda: {'two': torch.full((3,), 2.0), 'mone': torch.full((3,), -1.0)})
+        two, mone = norm['two'], norm['mone']
         cur, first = img, True
         pending_pool = None
         for op in vs.program:
             if op[0] == 'conv':
                 _, i, cin, cout = op
-                wts = self.devd(F.fold_vgg_conv(vsd, i))
+                wts = self.devd(f'vgg.conv{i}', lambda i=i: F.fold_vgg_conv(vsd, i))
                 t = Act(self, R, cur.h, cur.w, cout, f'vgg.conv{i}')
                 src = cur
                 if first:
@@ -520,7 +558,7 @@ class Engine:
                 cur = pl
         # head
         f = cur.h
-        head = self.devd(F.fold_vgg_head(vsd, vs.feat_channels, f))
+        head = self.devd(f'vgg.head.f{f}', lambda: F.fold_vgg_head(vsd, vs.feat_channels, f))
         d = vs.head_dim
         feat = cur
         feat_flat = feat.t.view(R, 1, 1, f * f * feat.c)
@@ -541,6 +579,20 @@ class Engine:
         return out.t.view(R, vs.n_classes)
 
     # ------------------------------------------------------------------------------------------------ run
+    def set_alphas(self, alphas: Sequence[float]):
+        """`interpolation_alphas` is mutable in the reference (alpha learning overwrites it,
+        src/experiments/alpha_learning/common_utils.py:88): patch the sampler descriptors in place."""
+        alphas = [float(a) for a in alphas]
+        if len(alphas) != len(self.alphas):
+            raise ValueError(f'{len(self.alphas)} interpolation alphas expected, got {len(alphas)}')
+        if alphas == self.alphas:
+            return
+        self.alphas = alphas
+        for d, idx in self._sampler_descs:
+            d.alpha, d.one_minus_alpha = alphas[idx], 1.0 - alphas[idx]
+        self.fwd.finalize()
+        self.bwd.finalize()
+
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -556,10 +608,12 @@ class Engine:
             raise RuntimeError('engine was built without a backward plan')
         if self.dry_run:
             raise RuntimeError('dry-run engine: plans were built for validation only')
-        if not from_purified:
+        if self.dpurified is not None and not from_purified:
             self.dpurified.zero_()
         if from_logits:
             self.bwd.run(self.stream())
         else:
+            if not self.has_nvae:
+                raise RuntimeError('classifier-only engine: backward starts from the logits')
             self._purified_grad_nhwc.g.zero_()
             self.bwd.run(self.stream(), start=self.bwd_split)

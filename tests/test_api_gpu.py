@@ -1,0 +1,157 @@
+"""
+GPU: the drop-in surface (load(args) -> EoTWrapper(NVAEDefenseModel(CelebaIdentityClassifier))) driven the way the
+reference's driver and attacks drive it (src/experiments/test_defense.py:133-135,225; src/attacks/untargeted.py:146,
+529-535), checked against the oracle with explicit noise.
+"""
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd.experiments.load_defense import load   # noqa: E402
+from gen_adversarial_amd.nvae_spec import build_spec, nvae_checkpoint   # noqa: E402
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   # noqa: E402
+from oracle import defender_oracle as D   # noqa: E402
+
+DEV = 'cuda:0'
+CFG = {'initial_channels': 8, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 2, 'num_scales': 3,
+       'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
+       'num_latent_per_group': 4, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+RES = (3, 64, 64)
+EOT = 4
+
+
+@pytest.fixture(scope='module')
+def setup(tmp_path_factory):
+    d = tmp_path_factory.mktemp('ckpt')
+    ck = nvae_checkpoint(CFG, RES, seed=5)
+    torch.save(ck, d / 'nvae.pt')
+    vsd = init_vgg_state_dict(100, 16, seed=6)
+    torch.save({'state_dict': vsd}, d / 'vgg.pt')
+    n_groups = len(build_spec(CFG, RES).groups)
+    alphas = [round(i / (n_groups - 1), 3) for i in range(n_groups)]
+    y = {'classifier_path': str(d / 'vgg.pt'), 'autoencoder_path': str(d / 'nvae.pt'), 'interpolation_alphas': alphas,
+         'alpha_attenuation': 0.7, 'initial_noise_eps': 2.0, 'gaussian_blur_input': False}
+    with open(d / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump(y, f)
+    args = Namespace(config=str(d / 'cfg.yaml'), experiment='ids', defense_type='ours', eot_steps=EOT, device=DEV)
+    args, model = load(args)
+    return args, model, ck, vsd, [a * 0.7 for a in alphas]
+
+
+def _oracle(setup, x, eps, noise, rep):
+    _, _, ck, vsd, alphas = setup
+    spec = build_spec(CFG, RES)
+    sd = ck['state_dict_temp=0.6']
+    return D.nvae_defender(sd, spec, vsd, build_vgg_spec(100, 16), x.repeat_interleave(rep, dim=0), alphas, eps, noise, 2.0)
+
+
+def test_eot_logits_grad_and_retain_graph(setup):
+    args, model, *_ = setup
+    assert args.image_size == 64 and 'pgd' in args.attacks
+    spec = build_spec(CFG, RES)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(1, *RES, generator=g)
+    eps = [torch.randn(EOT, 4, gs.res, gs.res, generator=g) for gs in spec.groups]
+    noise = torch.randn(EOT, *RES, generator=g)
+    xr = x.clone().requires_grad_(True)
+    lo, _ = _oracle(setup, xr, eps, noise, EOT)
+    lo = lo.mean(dim=0, keepdim=True)
+    g0, g3 = (torch.autograd.grad(lo[0, k], [xr], retain_graph=True)[0] for k in (0, 3))
+
+    model.model.fixed_noise([e.to(DEV) for e in eps], noise.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    assert out.shape == (1, 100)
+    assert (out.cpu() - lo).abs().max().item() < 2e-4
+    # per-class backward passes on one forward, as DeepFool / FAB do
+    h0 = torch.autograd.grad(out[0, 0], [xd], retain_graph=True)[0]
+    h3 = torch.autograd.grad(out[0, 3], [xd], retain_graph=True)[0]
+    assert (h0.cpu() - g0).abs().max().item() < 2e-4 * max(1.0, g0.abs().max().item())
+    assert (h3.cpu() - g3).abs().max().item() < 2e-4 * max(1.0, g3.abs().max().item())
+    # a second forward in between must not corrupt a later backward of the first graph
+    with torch.no_grad():
+        model(torch.rand(1, *RES, device=DEV))
+    model.model.fixed_noise([e.to(DEV) for e in eps], noise.to(DEV))
+    h0b = torch.autograd.grad(out[0, 0], [xd])[0]
+    assert (h0b - h0).abs().max().item() < 1e-6
+    model.model.fixed_noise(None, None)
+
+
+def test_get_purified_and_preds(setup):
+    args, model, *_ = setup
+    x = torch.rand(2, *RES, device=DEV)
+    logits, purified = model.model(x, preds_only=False)
+    assert logits.shape == (2, 100) and purified.shape == (2, *RES)
+    assert 0.0 <= purified.min().item() and purified.max().item() <= 1.0
+    p = model.get_purified(x)
+    assert p.shape == (2, *RES)
+    # purify() alone has no input-noise stage (eps=2 would move the image visibly)
+    spec = build_spec(CFG, RES)
+    eps = [torch.randn(2, 4, gs.res, gs.res, device=DEV) for gs in spec.groups]
+    model.model.fixed_noise(eps, None)
+    a = model.model.purify(x)
+    b = model.model.purify(x)
+    assert torch.equal(a, b)
+    model.model.fixed_noise(None, None)
+
+
+def test_alpha_overwrite_is_picked_up(setup):
+    """alpha learning assigns a new list to .interpolation_alphas (alpha_learning/common_utils.py:88)."""
+    args, model, *_ = setup
+    spec = build_spec(CFG, RES)
+    x = torch.rand(1, *RES, device=DEV)
+    eps = [torch.randn(EOT, 4, gs.res, gs.res, device=DEV) for gs in spec.groups]
+    noise = torch.randn(EOT, *RES, device=DEV)
+    model.model.fixed_noise(eps, noise)
+    old = list(model.model.interpolation_alphas)
+    with torch.no_grad():
+        l1 = model(x).clone()
+        model.model.interpolation_alphas = [0.0 for _ in old]
+        l2 = model(x).clone()
+        model.model.interpolation_alphas = old
+        l3 = model(x).clone()
+    assert not torch.equal(l1, l2) and torch.equal(l1, l3)
+    model.model.fixed_noise(None, None)
+
+
+def test_pgd_attack_protocol(setup):
+    args, model, *_ = setup
+    x = torch.rand(1, *RES, device=DEV)
+    with torch.no_grad():
+        label = model(x).argmax(dim=1)
+    atk = args.attacks['pgd']
+    atk.steps = 3
+    success, bound, adv = atk(x, label, model)
+    assert isinstance(success, bool) and isinstance(bound, float) and adv.shape == x.shape
+    assert bound <= 8.0 / 255.0 + 1e-6 and 0.0 <= adv.min().item() and adv.max().item() <= 1.0
+
+
+def test_base_classifier_path(setup, tmp_path):
+    """defense_type 'base' (configs/no_defense_ids.yaml): classifier only, differentiable."""
+    args, _, ck, vsd, _ = setup
+    y = {'classifier_path': yaml.safe_load(open(args.config))['classifier_path']}
+    with open(tmp_path / 'base.yaml', 'w') as f:
+        yaml.safe_dump(y, f)
+    a2, clf = load(Namespace(config=str(tmp_path / 'base.yaml'), experiment='ids', defense_type='base', eot_steps=1, device=DEV))
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, *RES, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = D.classifier_call(vsd, build_vgg_spec(100, 16), xr)
+    (gr,) = torch.autograd.grad(ref[:, 7].sum(), [xr])
+    xd = x.to(DEV).requires_grad_(True)
+    out = clf(xd)
+    assert (out.cpu() - ref).abs().max().item() < 2e-4
+    (gd,) = torch.autograd.grad(out[:, 7].sum(), [xd])
+    diff = (gd.cpu() - gr)
+    assert (diff.norm() / gr.norm()).item() < 2e-2          # max-pool near-ties: see test_engine_gpu
+    assert clf.get_purified(x) is x
+    with pytest.raises(NotImplementedError):
+        load(Namespace(config=args.config, experiment='gender', defense_type='ours', eot_steps=1, device=DEV))
