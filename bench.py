@@ -81,8 +81,12 @@ def cpu_baseline(model, rows, rep):
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, build_spec
     sd, vsd, vspec, alphas = model
     spec = build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION)
-    cores = os.cpu_count() or 1
-    threads = min(cores, int(os.environ.get('GA_CPU_THREADS', cores)))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    # a one-GPU box gives this process a 16-CPU share whatever the host's core count (oversubscribing stalls OpenMP)
+    threads = int(os.environ.get('GA_CPU_THREADS', min(cores, 16)))
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
     x = torch.rand(rows // rep, 3, 64, 64, generator=g).requires_grad_(True)
@@ -96,7 +100,11 @@ def cpu_baseline(model, rows, rep):
     dt = time.time() - t0
     return {'value': rows / dt, 'unit': 'rows/s', 'cores': threads, 'kind': 'port',
             'sample': f'{rows // rep} image(s) x EoT {rep} = {rows} rows, one attack step (forward + input-gradient), '
-                      f'{dt:.1f} s; autograd also forms weight gradients as the reference does'}
+                      f'{dt:.1f} s of oracle (PyTorch CPU fp32) time, dX only'}
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
 def main():
@@ -122,7 +130,9 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
 
+    log(f'rank {rank}/{world}: building weights + engine ({args.rows} rows)')
     eng, model = build_model(device, args.rows, args.eot, seed=0)
+    log(f'engine ready: {eng.bytes / 1e9:.1f} GB activations, {len(eng.fwd)} fwd + {len(eng.bwd)} bwd ops')
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.rand(args.rows // args.eot, 3, 64, 64, device=device, generator=g)
     # labels = clean prediction of the defender, so that the attack starts from "correct" 
@@ -135,6 +145,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    log('warmup done')
 
     def sync():
         torch.cuda.synchronize()
@@ -161,6 +172,7 @@ def main():
     dt = float(t.item())
 
     if rank == 0:
+        log(f'timed region: {dt:.3f} s for {args.steps} steps')
         rows_total = args.rows * world * args.steps
         # ---- roofline of the dominant kernel (conv_mfma_kernel): HIP events on the plan's stream, per launch
         s = eng.stream()
@@ -192,7 +204,9 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                out['cpu_baseline'] = cpu_baseline(model, args.eot, args.eot)
+                log('cpu baseline (oracle on host cores) ...')
+                out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot)
+                log('cpu baseline done')
             except Exception as ex:   # the baseline is a reported number, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'rows/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {ex}'}
         print(json.dumps(out))

@@ -1,0 +1,175 @@
+"""
+Multi-GPU evaluation driver: the counterpart of the reference's src/experiments/test_defense.py (one process per GPU,
+images sharded across ranks, every image attacked independently, results gathered and merged into results.json).
+
+Kept from the reference: CLI flags (test_defense.py:55-71), `DistributedSampler(shuffle=False)` sharding — rank r takes
+indices r::W of the head-padded index list (:116) — rank-major concatenation of the gathered results (:250-253),
+results.json keys and the 100.0 = "attack failed" convention (:141-146, 255-291), seeds (:93-97).
+Changed for MI355X: the four all_gathers (:245-248) are ONE RCCL all-gather of a (ceil(N/W), 1+#attacks) fp32 tensor;
+the per-image barrier (:126-127) is dropped (images are independent; a single barrier precedes the gather);
+ranks are launched by torchrun / mp.spawn with MASTER_ADDR=127.0.0.1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import random
+from datetime import timedelta
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FAILED = 100.0
+
+
+def shard_indices(n: int, rank: int, world: int) -> List[int]:
+    """torch.utils.data.DistributedSampler(shuffle=False, drop_last=False): pad with the head, take rank::world."""
+    per = math.ceil(n / world)
+    idx = list(range(n))
+    total = per * world
+    while len(idx) < total:
+        idx += idx[:total - len(idx)]
+    return idx[rank:total:world]
+
+
+def seed_everything(seed: int = 42):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def evaluate_shard(defense_model, attacks: Dict[str, Callable], images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """per image: [clean correct (0/1), distortion per attack] — the loop of test_defense.py:123-200, one image at a time
+    exactly as the reference drives its attacks."""
+    out = torch.zeros(images.shape[0], 1 + len(attacks))
+    for i in range(images.shape[0]):
+        x = images[i:i + 1].clamp(0.0, 1.0)
+        y = labels[i:i + 1]
+        with torch.no_grad():
+            out[i, 0] = float((defense_model(x).argmax(dim=1) == y).item())
+        for j, (_, attack) in enumerate(attacks.items()):
+            success, bound, _ = attack(x, y, defense_model)
+            out[i, 1 + j] = float(bound) if success else FAILED
+    return out
+
+
+def gather_results(local: torch.Tensor, world: int, device) -> torch.Tensor:
+    """ONE all-gather of the whole per-image table (payload: a few KB -> latency bound on xGMI)."""
+    if world == 1:
+        return local
+    local = local.to(device)
+    parts = [torch.zeros_like(local) for _ in range(world)]
+    dist.barrier()
+    dist.all_gather(parts, local)
+    return torch.cat(parts, dim=0).cpu()                       # rank-major, like test_defense.py:250-253
+
+
+def merge_results(path: str, clean: float, columns: Dict[str, List[float]]):
+    """read-modify-write of results.json (test_defense.py:255-291)."""
+    res = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            res = json.load(f)
+    res['Clean'] = clean
+    res.update(columns)
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    with open(path, 'w') as f:
+        json.dump(res, f)
+    return res
+
+
+def robust_accuracy(distortions: Sequence[float], eps: float) -> float:
+    """robust-acc@eps = mean(distortion > eps) with failure = 100 and clean-misclassified = 0."""
+    d = np.asarray(distortions, dtype=np.float64)
+    return float((d > eps).mean()) if d.size else float('nan')
+
+
+def run_worker(rank: int, world: int, args, make_model: Callable, dataset: Tuple[torch.Tensor, torch.Tensor],
+               backend: str = 'nccl', results_path: str = None):
+    """one rank: shard, evaluate, gather, merge.  `make_model(args) -> (args, defense_model)` is load_defense.load."""
+    seed_everything(42)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '12355')
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(hours=12))
+    args, defense_model = make_model(args)
+    images, labels = dataset
+    mine = shard_indices(images.shape[0], rank, world)
+    dev = args.device
+    local = evaluate_shard(defense_model, args.attacks, images[mine].to(dev), labels[mine].to(dev))
+    table = gather_results(local, world, dev)
+    res = None
+    if rank == 0:
+        cols = {name: table[:, 1 + j].tolist() for j, name in enumerate(args.attacks.keys())}
+        res = merge_results(results_path or os.path.join(args.results_folder, 'results.json'),
+                            float(table[:, 0].mean().item()), cols)
+    if world > 1:
+        dist.barrier()
+    return res
+
+
+def synthetic_dataset(n: int, size: int, n_classes: int, seed: int = 0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, 3, size, size, generator=g), torch.randint(0, n_classes, (n,), generator=g)
+
+
+def folder_dataset(folder: str, size: int):
+    """<folder>/<class>/<image>: label = index of the parent directory (data/datasets.py:35-58); I/O is outside the
+    accelerated path and kept minimal (PIL + antialiased bilinear resize)."""
+    from PIL import Image
+    classes = sorted(d for d in os.listdir(folder) if os.path.isdir(os.path.join(folder, d)))
+    xs, ys = [], []
+    for ci, c in enumerate(classes):
+        for f in sorted(os.listdir(os.path.join(folder, c))):
+            im = Image.open(os.path.join(folder, c, f)).convert('RGB')
+            t = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+            t = torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', antialias=True, align_corners=False)
+            xs.append(t[0])
+            ys.append(ci)
+    return torch.stack(xs), torch.tensor(ys)
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser('Common Pipeline to test a given defense mechanism.')
+    p.add_argument('--images_path', type=str, default=None, help='All images in this folder will be attacked')
+    p.add_argument('--synthetic', type=int, default=0, help='use N synthetic images instead of --images_path')
+    p.add_argument('--eot_steps', type=int, default=32)
+    p.add_argument('--defense_type', type=str, choices=['base', 'A-VAE', 'ND-VAE', 'trades', 'ours', 'ablation'])
+    p.add_argument('--experiment', type=str, choices=['gender', 'ids', 'cars'])
+    p.add_argument('--config', type=str, required=True)
+    p.add_argument('--attack', type=str, default=None)
+    args = p.parse_args(argv)
+    args.results_folder = f'./results/{args.config.split("/")[-1][:-5]}/'
+    os.makedirs(args.results_folder, exist_ok=True)
+    return args
+
+
+def main():
+    from .load_defense import load
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    args.device = f'cuda:{local_rank}'
+
+    def make_model(a):
+        a, m = load(a)
+        if a.attack is not None:
+            a.attacks = {k: v for k, v in a.attacks.items() if k == a.attack}
+        return a, m
+    size = {'ids': 64, 'gender': 256, 'cars': 128}[args.experiment]
+    data = synthetic_dataset(args.synthetic, size, 100) if args.synthetic else folder_dataset(args.images_path, size)
+    res = run_worker(rank, world, args, make_model, data, backend='nccl')
+    if rank == 0:
+        print(json.dumps({k: (v if not isinstance(v, list) else f'{len(v)} values') for k, v in res.items()}))
+
+
+if __name__ == '__main__':
+    main()

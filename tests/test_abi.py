@@ -1,0 +1,41 @@
+"""CPU: the C-ABI library loads, exports every symbol include/ga_ops.h declares, and its descriptors reject bad
+arguments before touching the GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+from gen_adversarial_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'ga_ops.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ga_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = _declared()
+    assert len(names) >= 16 and set(names) == set(L.EXPORTS)
+    for n in names:
+        assert getattr(L.lib, n) is not None
+
+
+def test_struct_sizes_and_version():
+    assert L.lib.ga_abi_version() == 1
+    assert L.lib.ga_sizeof_op() == C.sizeof(L.Op)
+
+
+def test_bad_descriptors_are_rejected_without_a_gpu():
+    for desc, fn in ((L.ConvDesc(), L.lib.ga_conv2d), (L.DwDesc(), L.lib.ga_dwconv5), (L.ReduceDesc(), L.lib.ga_rowchan_reduce),
+                     (L.SeExciteDesc(), L.lib.ga_se_excite), (L.SeApplyDesc(), L.lib.ga_se_apply),
+                     (L.BilinearBwdDesc(), L.lib.ga_bilinear_up2_bwd), (L.SamplerDesc(), L.lib.ga_sampler_mix),
+                     (L.DmlDesc(), L.lib.ga_dml_mean), (L.MaxpoolDesc(), L.lib.ga_maxpool2), (L.ImageIoDesc(), L.lib.ga_image_io)):
+        assert fn(C.byref(desc), None) == -1
+    assert L.lib.ga_plan_run(None, 0, None, None) == -1
+    d = L.DwDesc()
+    d.x = d.w = d.y = 16
+    d.N = d.H = d.W = 1
+    d.C = 6                                       # channel count the kernel does not implement
+    assert L.lib.ga_dwconv5(C.byref(d), None) == -3

@@ -1,0 +1,169 @@
+"""CPU: host logic — weight folding against the oracle, plan construction (dry run), FLOP accounting against SURVEY.md,
+the PGD step and the product path's refusal to run without a GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden_cfg
+from gen_adversarial_amd import _lib as L
+from gen_adversarial_amd import folding as FO
+from gen_adversarial_amd.attacks.pgd import PGDLinf
+from gen_adversarial_amd.engine import Engine, WeightStore
+from gen_adversarial_amd.nvae_spec import (ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, DecCellSpec, EncCellSpec, _Rng,
+                                           _dec_cell, _enc_cell, build_spec, init_nvae_state_dict)
+from gen_adversarial_amd.vgg_spec import adaptive_avgpool_matrix, build_vgg_spec, init_vgg_state_dict
+from oracle import defender_oracle as D
+from oracle import nvae_oracle as O
+
+
+def _conv_from_layout(x, w_flat, b, cout, cin, k, stride=1):
+    w = w_flat.reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+    return F.conv2d(x, w, b, stride=stride, padding=k // 2)
+
+
+@pytest.mark.parametrize('down', [False, True])
+def test_enc_cell_folding(down):
+    cell = EncCellSpec('c', 8, 16 if down else 8, down)
+    sd = {}
+    _enc_cell(sd, _Rng(1), cell)
+    w = FO.fold_enc_cell(sd, cell)
+    x = torch.randn(2, 8, 8, 8)
+    st = 2 if down else 1
+    a = F.silu(x * w['pro_scale'].view(1, -1, 1, 1) + w['pro_shift'].view(1, -1, 1, 1))
+    t1 = _conv_from_layout(a, w['w1'], w['b1'], cell.cout, 8, 3, st)
+    t2 = _conv_from_layout(F.silu(t1), w['w2'], w['b2'], cell.cout, cell.cout, 3)
+    gate = torch.sigmoid(F.linear(F.relu(F.linear(t2.mean(dim=[2, 3]), w['se_w1'], w['se_b1'])), w['se_w2'], w['se_b2']))
+    skip = _conv_from_layout(F.silu(x), w['ws'], w['bs'], cell.cout, 8, 1, 2) if down else x
+    out = skip + 0.1 * gate.view(2, -1, 1, 1) * t2
+    np.testing.assert_allclose(out.numpy(), O.enc_cell(sd, cell, x).numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize('up', [False, True])
+def test_dec_cell_folding_and_commuted_upsampling(up):
+    cell = DecCellSpec('c', 8, 4 if up else 8, up, 6)
+    sd = {}
+    _dec_cell(sd, _Rng(2), cell)
+    w = FO.fold_dec_cell(sd, cell)
+    x = torch.randn(2, 8, 4, 4)
+    t1 = F.conv2d(x, w['w1'].view(cell.hidden, 8, 1, 1), w['b1'])               # low resolution: 1x1 before nearest-up
+    a = F.silu(t1)
+    if up:
+        a = F.interpolate(a, scale_factor=2, mode='nearest')
+    wd = w['wd'].t().reshape(cell.hidden, 1, 5, 5)
+    t2 = F.conv2d(a, wd, w['bd'], padding=2, groups=cell.hidden)
+    t3 = F.conv2d(F.silu(t2), w['w2'].view(cell.cout, cell.hidden, 1, 1), w['b2'])
+    gate = torch.sigmoid(F.linear(F.relu(F.linear(t3.mean(dim=[2, 3]), w['se_w1'], w['se_b1'])), w['se_w2'], w['se_b2']))
+    if up:
+        low = F.conv2d(x, w['ws'].view(cell.cout, 8, 1, 1), w['bs'])            # 1x1 before the bilinear interpolation
+        skip = F.interpolate(low, scale_factor=2, mode='bilinear', align_corners=True)
+    else:
+        skip = x
+    out = skip + 0.1 * gate.view(2, -1, 1, 1) * t3
+    np.testing.assert_allclose(out.numpy(), O.dec_cell(sd, cell, x).numpy(), atol=3e-6)
+    # backward layouts are the transposes / flips of the forward ones
+    assert torch.equal(w['w1_bwd'], w['w1'].t()) and torch.equal(w['w2_bwd'], w['w2'].t())
+    assert torch.equal(w['wd_bwd'].t().reshape(-1, 5, 5), wd[:, 0].flip(1, 2))
+
+
+def test_vgg_head_folding_is_exact_pooling():
+    spec = build_vgg_spec(10, 16)
+    sd = init_vgg_state_dict(10, 16, 3)
+    for f in (1, 2, 3):
+        feat = torch.randn(3, spec.feat_channels, f, f)
+        x = F.adaptive_avg_pool2d(F.relu(feat), (7, 7)).flatten(1)
+        x = F.linear(x, sd['model.classifier.0.weight'])
+        c = 'model.classifier.1'
+        ref = F.batch_norm(x, sd[f'{c}.running_mean'], sd[f'{c}.running_var'], sd[f'{c}.weight'], sd[f'{c}.bias'], False, 0.0, 1e-5)
+        h = FO.fold_vgg_head(sd, spec.feat_channels, f)
+        nhwc = F.relu(feat).permute(0, 2, 3, 1).reshape(3, -1)
+        np.testing.assert_allclose((nhwc @ h['w_head'].t() + h['b_head']).numpy(), ref.numpy(), atol=1e-5)
+    m = adaptive_avgpool_matrix(2, 7)
+    assert m.shape == (7, 2) and torch.allclose(m.sum(dim=1), torch.ones(7, dtype=torch.float64))
+    assert m[3].tolist() == [0.5, 0.5] and m[0].tolist() == [1.0, 0.0] and m[6].tolist() == [0.0, 1.0]
+
+
+def _flops(plan):
+    tot = 0
+    for d in plan.descs:
+        if isinstance(d, L.ConvDesc):
+            pix = d.N * d.Ho * d.Wo if d.sd == 1 else d.N * d.Hi * d.Wi
+            tot += 2 * pix * d.KH * d.KW * (d.C1 + d.C2) * d.Cout
+    return tot
+
+
+def test_assumed_config_plan_matches_survey_flop_count():
+    """15.15 GFLOP/row forward for the assumed NVAE config (we skip the unused log-sigma half of the
+    encoder samplers, apply the up-cell 1x1 convs before upsampling and fold the prior half of combiner_0:0,
+    so the plan is slightly BELOW the reference's count)."""
+    vspec = build_vgg_spec(100, 8)
+    vsd = init_vgg_state_dict(100, 8, 0)
+    sd = init_nvae_state_dict(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, 0)
+    n = len(build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION).groups)
+    assert n == 24
+    eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=1, rep=1, alphas=[0.5] * n,
+                 device='cpu', dry_run=True)
+    nvae_fwd = sum(2 * (d.N * d.Ho * d.Wo) * d.KH * d.KW * (d.C1 + d.C2) * d.Cout
+                   for d, nm in zip(eng.fwd.descs, eng.fwd.names) if isinstance(d, L.ConvDesc) and not nm.startswith('vgg'))
+    assert 13.5e9 < nvae_fwd < 15.2e9, nvae_fwd
+    nvae_bwd = sum((2 * (d.N * d.Ho * d.Wo if d.sd == 1 else d.N * d.Hi * d.Wi) * d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
+                   for d, nm in zip(eng.bwd.descs, eng.bwd.names) if isinstance(d, L.ConvDesc) and not nm.startswith('vgg'))
+    assert 0.9 * nvae_fwd < nvae_bwd < 1.1 * nvae_fwd
+    with pytest.raises(RuntimeError):
+        eng.forward()
+
+
+def test_plans_build_for_every_golden_config_and_share_weights(golden_cases):
+    for name, g in golden_cases.items():
+        cfg, res = golden_cfg(g)
+        sd = init_nvae_state_dict(cfg, res, 1)
+        vspec = build_vgg_spec(10, 16)
+        vsd = init_vgg_state_dict(10, 16, 2)
+        n = len(build_spec(cfg, res).groups)
+        store = WeightStore('cpu')
+        e1 = Engine(sd, cfg, res, vsd, vspec, rows=2, rep=1, alphas=[0.3] * n, device='cpu', dry_run=True, store=store)
+        b = store.bytes
+        e2 = Engine(sd, cfg, res, vsd, vspec, rows=4, rep=2, alphas=[0.3] * n, device='cpu', dry_run=True, store=store)
+        assert store.bytes == b and len(e1.fwd) == len(e2.fwd) and 0 < e1.bwd_split < len(e1.bwd)
+        e2.set_alphas([0.1] * n)
+        assert all(abs(d.alpha - 0.1) < 1e-7 for d, _ in e2._sampler_descs)
+        with pytest.raises(ValueError):
+            e2.set_alphas([0.1])
+
+
+def test_no_cpu_fallback():
+    cfg = dict(ASSUMED_NVAE_CONFIG)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        Engine({}, cfg, ASSUMED_NVAE_RESOLUTION, {}, build_vgg_spec(100, 8), rows=1, rep=1, alphas=[0.0] * 24, device='cpu')
+    from gen_adversarial_amd.defenses.ours.models import CelebaIdentityClassifier, E4EStyleGanDefenseModel
+    with pytest.raises(RuntimeError, match='GPU only'):
+        CelebaIdentityClassifier('/nonexistent', 'cpu')
+    with pytest.raises(NotImplementedError):
+        E4EStyleGanDefenseModel()
+
+
+def test_pgd_step_and_protocol_on_a_toy_net():
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 8 * 8, 5))
+    x = torch.rand(4, 3, 8, 8)
+    y = net(x).argmax(dim=1)
+    atk = PGDLinf(eps=8 / 255, step_size=2 / 255, steps=20)
+    success, bound, adv = atk(x, y, net)
+    assert adv.shape == x.shape and float(bound.max()) <= 8 / 255 + 1e-6
+    assert float(adv.min()) >= 0 and float(adv.max()) <= 1
+    assert torch.equal(net(adv).argmax(dim=1) != y, success)
+    s1, b1, a1 = atk(x[:1], y[:1], net)
+    assert isinstance(s1, bool) and isinstance(b1, float)
+    g = torch.ones_like(x)
+    nxt = PGDLinf.step(x, x, g, 0.01, 0.05)
+    assert float((nxt - x).abs().max()) <= 0.01 + 1e-7
+
+
+def test_oracle_noise_and_blur_helpers():
+    x = torch.rand(2, 3, 16, 16)
+    n = torch.randn(2, 3, 16, 16)
+    y = D.add_gaussian_noise(x, n, 2.0)
+    assert float(y.min()) >= 0 and float(y.max()) <= 1
+    assert D.blur_kernel_size(64) == 15 and D.blur_kernel_size(256) == 255   # abstract_models.py:153-156
+    b = D.apply_gaussian_blur(torch.rand(1, 3, 64, 64))
+    assert b.shape == (1, 3, 64, 64)
