@@ -30,7 +30,8 @@ class ConvDesc(C.Structure):
                 ('N', i32), ('Hi', i32), ('Wi', i32), ('C1', i32), ('C2', i32),
                 ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('sn', i32), ('sd', i32), ('pad', i32),
-                ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32)]
+                ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
+                ('splits', i32), ('ws', fp), ('ws_floats', C.c_long)]
 
 
 class DwDesc(C.Structure):
@@ -104,6 +105,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
+           'ga_plan_profile',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -126,6 +128,8 @@ def _load():
     lib.ga_plan_time.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.c_int, C.POINTER(f32), C.POINTER(f32),
                                  C.POINTER(C.c_long)]
     lib.ga_plan_time.restype = C.c_int
+    lib.ga_plan_profile.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(f32)]
+    lib.ga_plan_profile.restype = C.c_int
     lib.ga_last_hip_error.restype = C.c_char_p
     lib.ga_abi_version.restype = C.c_int
     lib.ga_sizeof_op.restype = C.c_ulong
@@ -203,6 +207,14 @@ class Plan:
         rc = lib.ga_plan_run(first, end - start, stream, C.byref(failed))
         if rc != 0:
             check(rc, f'plan op #{start + failed.value} ({self.names[start + failed.value]})')
+
+    def profile(self, stream: int = 0):
+        """per-op device milliseconds of one replay."""
+        if self._arr is None:
+            self.finalize()
+        out = (f32 * len(self.descs))()
+        check(lib.ga_plan_profile(self._arr, len(self.descs), stream, out), 'ga_plan_profile')
+        return list(out)
 
     def time(self, stream: int = 0, iters: int = 1, per_conv: bool = False):
         if self._arr is None:

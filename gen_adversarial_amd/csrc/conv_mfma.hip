@@ -12,8 +12,11 @@
 //   * 256 threads = 4 waves arranged WM x WN, each wave owns TM x TN tiles of 32x32; accumulators stay in registers
 //     for the whole K loop; global->register prefetch of tile t+1 overlaps the MFMAs of tile t (double-buffered
 //     LDS, one barrier per K tile).
-//   * Output channel sits on the lane (C/D layout: col = lane&31), so each accumulator register row is a 128-B
-//     contiguous NHWC store; bias / act' / addend are applied in the epilogue.
+//   * Epilogue: the accumulator tile is transposed through the (now free) LDS so that every lane handles 4
+//     consecutive channels of one pixel: bias / act' (reads the saved forward input) / addends / store are all 16-B
+//     accesses on 512-B contiguous rows.  A scalar epilogue remains for channel counts that are not multiples of 4.
+//   * Split-K (small M x Cout with a long K: samplers, the classifier head): grid.y = splits, raw partial tiles go to
+//     a caller-provided workspace and a second kernel sums them in a fixed order and applies the epilogue.
 //   * blockIdx is remapped so that consecutive logical tiles (which share the A panel) run on one XCD's L2.
 #include "ga_common.h"
 
@@ -22,11 +25,50 @@ namespace ga {
 constexpr int BK = 32;
 constexpr int LDK = 36;
 
+// epilogue on 4 consecutive channels of one output pixel (vector form)
+__device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, const int co, floatx4 v, const int HoWo) {
+    if (d.bias) v += *reinterpret_cast<const floatx4*>(d.bias + co);
+    if (d.dact_x) {
+        floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)m * d.lddact + co);
+        floatx4 ds = {1.f, 1.f, 1.f, 1.f};
+        if (d.dact_scale) {
+            ds = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
+            u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + co);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+    }
+    if (d.addend) {
+        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        v += *reinterpret_cast<const floatx4*>(d.addend + am * d.ldadd + co);
+    }
+    if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + (size_t)m * d.ldadd2 + co);
+    *reinterpret_cast<floatx4*>(d.y + (size_t)m * d.ldy + co) = v;
+}
+
+__device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, const int co, float v, const int HoWo) {
+    if (d.bias) v += d.bias[co];
+    if (d.dact_x) {
+        float ds = 1.f, db = 0.f;
+        if (d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
+        const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
+        v *= act_bwd_fast(u, d.dact_act) * ds;
+    }
+    if (d.addend) {
+        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        v += d.addend[am * d.ldadd + co];
+    }
+    if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
+    d.y[(size_t)m * d.ldy + co] = v;
+}
+
 template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ void __launch_bounds__(256)
-conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc) {
+conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
+                 const int vec_out) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int LDC = BN + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDK;
@@ -84,7 +126,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                             }
                             if (d.pro_act) {
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = act_fwd(v[e], d.pro_act);
+                                for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
                             }
                         } else {
                             v = *reinterpret_cast<const floatx4*>(d.x2 + pix * d.ldx2 + (c - d.C1));
@@ -99,7 +141,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                                     const size_t po = (d.pro_per_row ? (size_t)a_n[i] * d.C1 : 0) + ce;
                                     u = u * d.pro_scale[po] + d.pro_shift[po];
                                 }
-                                v[e] = act_fwd(u, d.pro_act);
+                                v[e] = act_fwd_fast(u, d.pro_act);
                             } else if (ce < Ctot) {
                                 v[e] = d.x2[pix * d.ldx2 + (ce - d.C1)];
                             }
@@ -143,15 +185,22 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- K range of this block (split-K: grid.y slices of whole K tiles)
     const int T = d.KH * d.KW * nkc;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int tper = (T + splits - 1) / splits;
+    const int t_begin = split * tper;
+    const int t_end = min(T, t_begin + tper);
 
     const int lrow = lane & 31, lh = lane >> 5;
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < T) load_tile(t + 1);
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) load_tile(t + 1);
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + 4 * lh;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + 4 * lh;
 #pragma unroll
@@ -169,67 +218,111 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < T) store_tile(buf ^ 1);
+        if (t + 1 < t_end) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    // ---- epilogue.  C/D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    float* ws = splits > 1 ? d.ws + (size_t)split * M * d.Cout : nullptr;
+    if (vec_out) {
+        float* Cs = smem;                                   // [BM][LDC], the K loop's buffers are free now
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + wn * TN * 32 + j * 32 + lrow;
-        if (co >= d.Cout) continue;
-        const float bias = d.bias ? d.bias[co] : 0.f;
-        float ds = 1.f, db = 0.f;
-        if (d.dact_x && d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bias;
-                if (d.dact_x) {
-                    const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
-                    v *= act_bwd(u, d.dact_act) * ds;
+                for (int r = 0; r < 16; ++r)
+                    Cs[(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
+        __syncthreads();
+        constexpr int QL = BN / 4;                          // channel-quads per row
+        constexpr int ROWS = 256 / QL;                      // rows per pass
+        const int q = tid % QL, rr = tid / QL;
+        const int co = n0 + 4 * q;
+        if (co < d.Cout) {
+#pragma unroll 4
+            for (int r = rr; r < BM; r += ROWS) {
+                const int m = m0 + r;
+                if (m >= M) break;
+                const floatx4 v = *reinterpret_cast<const floatx4*>(Cs + r * LDC + 4 * q);
+                if (ws) *reinterpret_cast<floatx4*>(ws + (size_t)m * d.Cout + co) = v;
+                else epilogue4(d, m, co, v, HoWo);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = n0 + wn * TN * 32 + j * 32 + lrow;
+            if (co >= d.Cout) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m >= M) continue;
+                    if (ws) ws[(size_t)m * d.Cout + co] = acc[i][j][r];
+                    else epilogue1(d, m, co, acc[i][j][r], HoWo);
                 }
-                if (d.addend) {
-                    const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
-                    v += d.addend[am * d.ldadd + co];
-                }
-                if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
-                d.y[(size_t)m * d.ldy + co] = v;
             }
         }
     }
 }
 
+// sums the split-K partial tiles in split order (bitwise reproducible) and applies the epilogue
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ga_conv_desc d, const int M, const int splits, const int vec_out) {
+    const int HoWo = d.Ho * d.Wo;
+    const size_t slab = (size_t)M * d.Cout;
+    if (vec_out) {
+        const long total4 = (long)slab / 4;
+        const int C4 = d.Cout / 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+            floatx4 v = *reinterpret_cast<const floatx4*>(d.ws + i * 4);
+            for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const floatx4*>(d.ws + s * slab + i * 4);
+            epilogue4(d, (int)(i / C4), (int)(i % C4) * 4, v, HoWo);
+        }
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < (long)slab; i += (long)gridDim.x * 256) {
+            float v = d.ws[i];
+            for (int s = 1; s < splits; ++s) v += d.ws[s * slab + i];
+            epilogue1(d, (int)(i / d.Cout), (int)(i % d.Cout), v, HoWo);
+        }
+    }
+}
+
 template <int WM, int WN, int TM, int TN>
-static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec) {
+static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int vec_out, int splits) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const int M = d.N * d.Ho * d.Wo;
     const int Ctot = d.C1 + d.C2;
     const int Ktot = d.KH * d.KW * Ctot;
     const int nkc = (Ctot + BK - 1) / BK;
     const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
-    const dim3 grid(tilesM * tilesN), block(256);
+    size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
+    const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    if (lds_c > lds) lds = lds_c;
+    const dim3 grid(tilesM * tilesN, splits), block(256);
     if (vec) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, true>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc);
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, true>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, false>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc);
+        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, false>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
     }
+    int rc = check_launch();
+    if (rc != GA_OK || splits == 1) return rc;
+    long items = (long)M * d.Cout / (vec_out ? 4 : 1);
+    long blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, M, splits, vec_out);
     return check_launch();
 }
 
@@ -250,17 +343,29 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     if (d.addend && d.ldadd < d.Cout) return GA_E_BADARG;
     if (d.addend2 && d.ldadd2 < d.Cout) return GA_E_BADARG;
     if (d.dact_x && d.lddact < d.Cout) return GA_E_BADARG;
-    // every output pixel must map inside the gather formula's domain (host-side shape check, no device faults)
     if ((long)d.N * d.Ho * d.Wo > 0x7fffffffL) return GA_E_UNSUPPORTED;
     if ((long)d.KH * d.KW * (d.C1 + d.C2) > 0x7fffffffL) return GA_E_UNSUPPORTED;
+    const long M = (long)d.N * d.Ho * d.Wo;
+    int splits = d.splits <= 1 ? 1 : d.splits;
+    if (splits > 1) {
+        if (!d.ws || d.ws_floats < (long)splits * M * d.Cout) return GA_E_BADARG;
+        const int T = d.KH * d.KW * ((d.C1 + d.C2 + 31) / 32);
+        if (splits > T) splits = T;
+        if (splits > 65535) return GA_E_UNSUPPORTED;
+    }
 
     const bool vec = (d.C1 % 4 == 0) && (d.C2 % 4 == 0) && (d.ldx % 4 == 0) && (d.C2 == 0 || d.ldx2 % 4 == 0) &&
                      aligned16(d.x) && aligned16(d.w) && (d.C2 == 0 || aligned16(d.x2)) &&
                      (!d.pro_scale || (aligned16(d.pro_scale) && aligned16(d.pro_shift)));
+    const bool vec_out = (d.Cout % 4 == 0) && (d.ldy % 4 == 0) && aligned16(d.y) && (!d.bias || aligned16(d.bias)) &&
+                         (!d.addend || (d.ldadd % 4 == 0 && aligned16(d.addend))) &&
+                         (!d.addend2 || (d.ldadd2 % 4 == 0 && aligned16(d.addend2))) &&
+                         (!d.dact_x || (d.lddact % 4 == 0 && aligned16(d.dact_x) &&
+                                        (!d.dact_scale || (aligned16(d.dact_scale) && aligned16(d.dact_shift))))) &&
+                         (splits == 1 || aligned16(d.ws));
 
     int tile = d.tile;
     if (tile == 0) {
-        const long M = (long)d.N * d.Ho * d.Wo;
         if (d.Cout <= 32) tile = 4;
         else if (d.Cout <= 64) tile = (M >= 128 * 256) ? 2 : 3;
         else {
@@ -272,10 +377,10 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
         }
     }
     switch (tile) {
-        case 1: return launch_conv<2, 2, 2, 2>(d, stream, vec);
-        case 2: return launch_conv<4, 1, 1, 2>(d, stream, vec);
-        case 3: return launch_conv<2, 2, 1, 1>(d, stream, vec);
-        case 4: return launch_conv<4, 1, 1, 1>(d, stream, vec);
+        case 1: return launch_conv<2, 2, 2, 2>(d, stream, vec, vec_out, splits);
+        case 2: return launch_conv<4, 1, 1, 2>(d, stream, vec, vec_out, splits);
+        case 3: return launch_conv<2, 2, 1, 1>(d, stream, vec, vec_out, splits);
+        case 4: return launch_conv<4, 1, 1, 1>(d, stream, vec, vec_out, splits);
         default: return GA_E_UNSUPPORTED;
     }
 }

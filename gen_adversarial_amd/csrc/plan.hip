@@ -75,6 +75,25 @@ extern "C" int ga_plan_time(const ga_op* ops, int n, void* stream_, int iters, f
     return rc;
 }
 
+// per-op device time of one replay (event pair around every op) — profiling aid for tools/ and bench.py
+extern "C" int ga_plan_profile(const ga_op* ops, int n, void* stream_, float* per_op_ms) {
+    if (!ops || n <= 0 || !per_op_ms) return GA_E_BADARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) hipEventCreate(&e);
+    int rc = GA_OK;
+    hipEventRecord(ev[0], stream);
+    for (int i = 0; i < n && rc == GA_OK; ++i) {
+        rc = run_one(ops[i], stream_);
+        hipEventRecord(ev[i + 1], stream);
+    }
+    hipStreamSynchronize(stream);
+    if (rc == GA_OK)
+        for (int i = 0; i < n; ++i) hipEventElapsedTime(&per_op_ms[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) hipEventDestroy(e);
+    return rc;
+}
+
 extern "C" const char* ga_last_hip_error(void) { return hipGetErrorString(ga::g_last_err); }
 extern "C" int ga_abi_version(void) { return 1; }
 extern "C" unsigned long ga_sizeof_op(void) { return sizeof(ga_op); }

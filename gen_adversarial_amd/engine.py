@@ -13,6 +13,8 @@ PyTorch is used for device memory and the current stream only; every arithmetic 
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -23,6 +25,26 @@ from .nvae_spec import DecCellSpec, EncCellSpec, NVAESpec, build_spec
 from .vgg_spec import VggSpec
 
 RES_SCALE = 0.1          # `0.1 * self.residual(x)` — architecture.py:133,183
+WS_FLOATS = 32 * 1024 * 1024     # split-K workspace shared by every conv of an engine (128 MB)
+TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
+_TUNE_CACHE: Optional[dict] = None
+
+
+def tune_cache() -> dict:
+    """(tile, splits) per conv shape, measured on an MI355X by Engine.autotune and kept in-tree."""
+    global _TUNE_CACHE
+    if _TUNE_CACHE is None:
+        _TUNE_CACHE = {}
+        if os.path.exists(TUNE_FILE):
+            with open(TUNE_FILE) as f:
+                _TUNE_CACHE = json.load(f)
+    return _TUNE_CACHE
+
+
+def conv_key(d) -> str:
+    return '_'.join(str(int(v)) for v in (
+        d.N * d.Ho * d.Wo, d.Cout, d.C1, d.C2, d.KH, d.sn, d.sd, d.Hi, d.pro_act, bool(d.pro_scale), d.pro_per_row,
+        bool(d.dact_x), d.dact_act, bool(d.addend), bool(d.addend2), d.addend_bcast_n))
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -332,9 +354,68 @@ class Engine:
             self.bwd_split = len(self.bwd)
             for step in reversed(self._bwd_steps[:n_nvae_steps]):
                 step()
+        self._bwd_steps = None
+        self.ws = self.alloc((WS_FLOATS,)) if not self.dry_run else None
+        self.apply_tuning(tune_cache())
+
+    # ------------------------------------------------------------------------------------------------ tuning
+    def _conv_descs(self):
+        return [d for plan in (self.fwd, self.bwd) for d in plan.descs if isinstance(d, L.ConvDesc)]
+
+    def apply_tuning(self, cache: dict):
+        """set (tile, splits) of every conv from the cache; shapes not in the cache keep the library heuristic."""
+        for d in self._conv_descs():
+            tile, splits = cache.get(conv_key(d), (0, 1))
+            need = splits * d.N * d.Ho * d.Wo * d.Cout
+            if splits > 1 and (self.ws is None or need > WS_FLOATS):
+                tile, splits = 0, 1
+            d.tile, d.splits = int(tile), int(splits)
+            d.ws, d.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
         self.fwd.finalize()
         self.bwd.finalize()
-        self._bwd_steps = None
+
+    def autotune(self, cache: Optional[dict] = None, reps: int = 3, save: Optional[str] = None, verbose: bool = False) -> dict:
+        """time every (tile, split-K) candidate of every distinct conv shape on this GPU and keep the fastest."""
+        if self.dry_run:
+            raise RuntimeError('autotune needs a GPU')
+        cache = tune_cache() if cache is None else cache
+        stream = self.stream()
+        for d in self._conv_descs():
+            key = conv_key(d)
+            if key in cache:
+                continue
+            M = d.N * d.Ho * d.Wo
+            T = d.KH * d.KW * ((d.C1 + d.C2 + 31) // 32)
+            best = None
+            for tile in (1, 2, 3, 4):
+                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32)}[tile]
+                if bn >= 2 * max(32, d.Cout) and tile != 4:
+                    continue
+                blocks = -(-M // bm) * -(-d.Cout // bn)
+                for splits in (1, 2, 4, 8, 16, 32):
+                    if splits > 1 and (blocks * splits > 2048 or T < 2 * splits or splits * M * d.Cout > WS_FLOATS):
+                        continue
+                    t = L.ConvDesc.from_buffer_copy(d)
+                    t.tile, t.splits = tile, splits
+                    t.ws, t.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
+                    L.run(t, stream)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        L.run(t, stream)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1) / reps
+                    if best is None or ms < best[0]:
+                        best = (ms, tile, splits)
+            cache[key] = (best[1], best[2])
+            if verbose:
+                print(f'tune {key}: tile {best[1]} splits {best[2]} {best[0] * 1e3:.1f} us', flush=True)
+        self.apply_tuning(cache)
+        if save:
+            with open(save, 'w') as f:
+                json.dump(cache, f, indent=0, sort_keys=True)
+        return cache
 
     def _build_nvae(self, x0: Act) -> Act:
         """NVAEDefenseModel.purify (models.py:160-274) on the NHWC image x0; returns the purified NHWC image."""

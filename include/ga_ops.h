@@ -48,6 +48,8 @@ enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3 
  *             + addend2[n,ho,wo,co]                                                                   (if addend2)
  * sn/sd: (stride,1) = forward strided conv; (1,stride) = its transpose (backward-to-input) with flipped weights.
  * addend may alias y (in-place accumulation of a gradient).
+ * splits > 1: K is cut into `splits` slices computed by separate workgroups into `ws`, then summed in slice order
+ * (deterministic) by a second kernel that applies the epilogue — for small N*Ho*Wo*Cout with a long K.
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct ga_conv_desc {
     const float* x;          int ldx;      /* [N,Hi,Wi,ldx], channels [0,C1) used */
@@ -69,6 +71,9 @@ typedef struct ga_conv_desc {
     int dact_act;
     int addend_bcast_n;                    /* addend is [Ho,Wo,ldadd], shared by all n */
     int tile;                              /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32 (M x N) */
+    int splits;                            /* split-K factor (<=1: none); needs ws */
+    float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
+    long ws_floats;
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
@@ -210,6 +215,9 @@ int ga_plan_run(const ga_op* ops, int n, void* stream, int* failed_index);
 /* timing helper for bench.py: runs the plan `iters` times between two hipEvents recorded on `stream`, returns ms,
  * and when conv_ms != NULL also the summed duration of the GA_OP_CONV launches (per-op events). */
 int ga_plan_time(const ga_op* ops, int n, void* stream, int iters, float* total_ms, float* conv_ms, long* conv_launches);
+
+/* per-op device time (ms) of one replay: per_op_ms[n] written */
+int ga_plan_profile(const ga_op* ops, int n, void* stream, float* per_op_ms);
 
 const char* ga_last_hip_error(void);
 int ga_abi_version(void);

@@ -142,6 +142,28 @@ def test_conv_dual_source_bcast_addend_and_accumulate():
     close(nchw(y), ref + F.conv2d(torch.cat([x1, x2], 1), w) + a2, 2e-5, 'accumulate')
 
 
+@pytest.mark.parametrize('N,H,Cin,Cout,K,splits,tile', [(2, 4, 512, 20, 3, 8, 4), (4, 1, 1000, 100, 1, 16, 3),
+                                                        (2, 8, 64, 6, 3, 4, 0), (1, 4, 96, 40, 1, 32, 0)])
+def test_conv_split_k(N, H, Cin, Cout, K, splits, tile):
+    pad = K // 2
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, K, K, seed=2, scale=1.0 / np.sqrt(Cin * K * K))
+    b = g(Cout, seed=3)
+    add = g(N, Cout, H, H, seed=4)
+    ref = F.conv2d(F.silu(x), w, b, padding=pad) + add
+    y = nhwc(add)                                           # accumulate in place: addend aliases y
+    ws = torch.empty(splits * N * H * H * Cout, device=DEV)
+    run_conv(nhwc(x), fwd_w(w), y, K, pad=pad, tile=tile, bias=b.to(DEV), pro_act=1, addend=y, ldadd=Cout,
+             splits=splits, ws=ws, ws_floats=ws.numel())
+    close(nchw(y), ref, 2e-5, 'split-K')
+    d = L.ConvDesc()
+    d.x = d.w = d.y = 16
+    d.N = d.Hi = d.Wi = d.Ho = d.Wo = d.C1 = d.Cout = d.KH = d.KW = d.sn = d.sd = 1
+    d.ldx = d.ldy = 1
+    d.splits = 2                                            # no workspace
+    assert L.lib.ga_conv2d(C.byref(d), None) == -1
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)

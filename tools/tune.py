@@ -1,0 +1,18 @@
+"""GPU tool: autotune (tile, split-K) of every conv shape of the bench engine; writes the table under gpurun_out/."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import build_model
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+out = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/conv_tune_gfx950.json'
+eng, _ = build_model('cuda:0', R, 32)
+eng.x_in.uniform_()
+for e in eng.eps: e.normal_()
+eng.forward(); eng.dlogits.normal_(); eng.backward(); torch.cuda.synchronize()
+s = eng.stream()
+f0, fc0, _ = eng.fwd.time(s, iters=3, per_conv=True); b0, bc0, _ = eng.bwd.time(s, iters=3, per_conv=True)
+print(f'before: fwd {f0:.2f} (conv {fc0:.2f})  bwd {b0:.2f} (conv {bc0:.2f})', flush=True)
+cache = eng.autotune(reps=5, save=out, verbose=True)
+f1, fc1, _ = eng.fwd.time(s, iters=3, per_conv=True); b1, bc1, _ = eng.bwd.time(s, iters=3, per_conv=True)
+print(f'after : fwd {f1:.2f} (conv {fc1:.2f})  bwd {b1:.2f} (conv {bc1:.2f})  entries {len(cache)}')
