@@ -62,7 +62,8 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
     d.y[(size_t)m * d.ldy + co] = v;
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+// PRO: 0 = no prologue, 1 = per-channel affine and/or activation, 2 = per-(row,channel) affine (+ activation)
+template <int WM, int WN, int TM, int TN, bool VEC, int PRO>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
                  const int vec_out) {
@@ -99,39 +100,75 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         } else { a_n[i] = -1; a_h0[i] = 0; a_w0[i] = 0; }
     }
 
-    floatx4 ra[RA], rb[RB];
+    // ---- tile staging, split in two so that the global loads of tile t+1 are IN FLIGHT while tile t's MFMAs run:
+    //      issue_tile(): address math + unconditional loads (out-of-range lanes read a safe address and are zeroed
+    //      later: no divergent branch, hence no s_waitcnt, sits between a load and the MFMAs);
+    //      finish_tile(): prologue math on the landed registers + LDS writes, after the MFMAs.
+    floatx4 ra[RA], rb[RB], rs[PRO == 2 ? RA : 1], rt[PRO == 2 ? RA : 1];
+    unsigned okmask = 0;
+    int cur_c = 0;
+    const int sd_shift = d.sd > 1 ? 31 - __builtin_clz(d.sd) : 0, sd_mask = d.sd - 1;   // sd is a power of two
 
-    auto load_tile = [&](const int t) {
+    auto issue_tile = [&](const int t) {
         const int tap = t / nkc, c0 = (t - tap * nkc) * BK;
         const int kh = tap / d.KW, kw = tap - kh * d.KW;
         const int c = c0 + 4 * c4;
+        cur_c = c;
+        okmask = 0;
+        if (VEC) {
+            const bool first = c < d.C1;
+            const bool cok = c < Ctot;
+            const float* src[RA];
+            const float* wsrc[RB];
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            floatx4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_n[i] >= 0 && c < Ctot) {
+            for (int i = 0; i < RA; ++i) {
                 int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-                bool ok = (hi >= 0) & (wi >= 0);
-                if (d.sd != 1) { ok = ok && (hi % d.sd == 0) && (wi % d.sd == 0); hi /= d.sd; wi /= d.sd; }
-                ok = ok && hi < d.Hi && wi < d.Wi;
-                if (ok) {
-                    const size_t pix = ((size_t)a_n[i] * d.Hi + hi) * d.Wi + wi;
-                    if (VEC) {
-                        if (c < d.C1) {
-                            v = *reinterpret_cast<const floatx4*>(d.x + pix * d.ldx + c);
-                            if (d.pro_scale) {
-                                const size_t po = (d.pro_per_row ? (size_t)a_n[i] * d.C1 : 0) + c;
-                                const floatx4 s = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
-                                const floatx4 b = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
-                                v = v * s + b;
-                            }
-                            if (d.pro_act) {
+                bool ok = cok & (a_n[i] >= 0) & (hi >= 0) & (wi >= 0) & (((hi | wi) & sd_mask) == 0);
+                hi >>= sd_shift; wi >>= sd_shift;
+                ok = ok & (hi < d.Hi) & (wi < d.Wi);
+                const size_t pix = ((size_t)a_n[i] * d.Hi + hi) * d.Wi + wi;
+                const size_t o1 = ok ? pix * d.ldx + c : 0;
+                const size_t o2 = ok ? pix * d.ldx2 + (c - d.C1) : 0;
+                src[i] = (first | !ok) ? d.x + o1 : d.x2 + o2;
+                okmask |= (ok ? 1u : 0u) << i;
+            }
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
-                            }
-                        } else {
-                            v = *reinterpret_cast<const floatx4*>(d.x2 + pix * d.ldx2 + (c - d.C1));
-                        }
-                    } else {
+            for (int i = 0; i < RB; ++i) {
+                const int co = n0 + r0 + 32 * i;
+                const bool ok = (co < d.Cout) & cok;
+                wsrc[i] = d.w + (ok ? (size_t)co * Ktot + (size_t)tap * Ctot + c : 0);
+                okmask |= (ok ? 1u : 0u) << (16 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const floatx4*>(src[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const floatx4*>(wsrc[i]);
+            if (PRO == 1) {
+                if (d.pro_scale) {
+                    const int pc = first ? c : 0;
+                    rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
+                    rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
+                }
+            } else if (PRO == 2) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const size_t po = (first && ((okmask >> i) & 1u)) ? (size_t)a_n[i] * d.C1 + c : 0;
+                    rs[i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
+                    rt[i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
+                }
+            }
+        } else {
+            // scalar path (channel counts that are not multiples of 4: the 3-channel image, odd latent sizes)
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (a_n[i] >= 0 && c < Ctot) {
+                    int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                    bool ok = (hi >= 0) & (wi >= 0);
+                    if (d.sd != 1) { ok = ok && (hi % d.sd == 0) && (wi % d.sd == 0); hi /= d.sd; wi /= d.sd; }
+                    ok = ok && hi < d.Hi && wi < d.Wi;
+                    if (ok) {
+                        const size_t pix = ((size_t)a_n[i] * d.Hi + hi) * d.Wi + wi;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int ce = c + e;
@@ -148,33 +185,56 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                         }
                     }
                 }
+                ra[i] = v;
             }
-            ra[i] = v;
-        }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            floatx4 v = {0.f, 0.f, 0.f, 0.f};
-            const int co = n0 + r0 + 32 * i;
-            if (co < d.Cout && c < Ctot) {
-                const float* wp = d.w + (size_t)co * Ktot + (size_t)tap * Ctot + c;
-                if (VEC) {
-                    v = *reinterpret_cast<const floatx4*>(wp);
-                } else {
+            for (int i = 0; i < RB; ++i) {
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                const int co = n0 + r0 + 32 * i;
+                if (co < d.Cout && c < Ctot) {
+                    const float* wp = d.w + (size_t)co * Ktot + (size_t)tap * Ctot + c;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) if (c + e < Ctot) v[e] = wp[e];
                 }
+                rb[i] = v;
             }
-            rb[i] = v;
         }
     };
 
-    auto store_tile = [&](const int buf) {
+    auto finish_tile = [&](const int buf) {
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (VEC) {
+            const bool first = cur_c < d.C1;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<floatx4*>(Ab + (r0 + 32 * i) * LDK + 4 * c4) = ra[i];
+            for (int i = 0; i < RA; ++i) {
+                floatx4 v = ra[i];
+                if (PRO != 0) {
+                    floatx4 pv = v;
+                    if (PRO == 2) pv = pv * rs[i] + rt[i];
+                    else if (d.pro_scale) pv = pv * rs[0] + rt[0];
+                    if (d.pro_act == GA_ACT_SILU) {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<floatx4*>(Bb + (r0 + 32 * i) * LDK + 4 * c4) = rb[i];
+                        for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
+                    } else if (d.pro_act != GA_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] = act_fwd_fast(pv[e], d.pro_act);
+                    }
+                    v = first ? pv : v;
+                }
+                v = (okmask >> i) & 1u ? v : zero;
+                *reinterpret_cast<floatx4*>(Ab + (r0 + 32 * i) * LDK + 4 * c4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                *reinterpret_cast<floatx4*>(Bb + (r0 + 32 * i) * LDK + 4 * c4) = (okmask >> (16 + i)) & 1u ? rb[i] : zero;
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) *reinterpret_cast<floatx4*>(Ab + (r0 + 32 * i) * LDK + 4 * c4) = ra[i];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *reinterpret_cast<floatx4*>(Bb + (r0 + 32 * i) * LDK + 4 * c4) = rb[i];
+        }
     };
 
     floatx16 acc[TM][TN];
@@ -194,13 +254,13 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
 
     const int lrow = lane & 31, lh = lane >> 5;
     if (t_begin < t_end) {
-        load_tile(t_begin);
-        store_tile(0);
+        issue_tile(t_begin);
+        finish_tile(0);
     }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) load_tile(t + 1);
+        if (t + 1 < t_end) issue_tile(t + 1);
         const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + lrow) * LDK + 4 * lh;
         const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + lrow) * LDK + 4 * lh;
 #pragma unroll
@@ -218,7 +278,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
         }
-        if (t + 1 < t_end) store_tile(buf ^ 1);
+        if (t + 1 < t_end) finish_tile(buf ^ 1);
         __syncthreads();
     }
 
@@ -239,13 +299,69 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         const int q = tid % QL, rr = tid / QL;
         const int co = n0 + 4 * q;
         if (co < d.Cout) {
-#pragma unroll 4
-            for (int r = rr; r < BM; r += ROWS) {
-                const int m = m0 + r;
-                if (m >= M) break;
-                const floatx4 v = *reinterpret_cast<const floatx4*>(Cs + r * LDC + 4 * q);
-                if (ws) *reinterpret_cast<floatx4*>(ws + (size_t)m * d.Cout + co) = v;
-                else epilogue4(d, m, co, v, HoWo);
+            constexpr int NB = (BM / ROWS) < 4 ? (BM / ROWS) : 4;      // rows handled together: loads first, math after
+            floatx4 bias4 = {0.f, 0.f, 0.f, 0.f}, ds4 = {1.f, 1.f, 1.f, 1.f}, dt4 = {0.f, 0.f, 0.f, 0.f};
+            if (!ws) {
+                if (d.bias) bias4 = *reinterpret_cast<const floatx4*>(d.bias + co);
+                if (d.dact_x && d.dact_scale) {
+                    ds4 = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
+                    dt4 = *reinterpret_cast<const floatx4*>(d.dact_shift + co);
+                }
+            }
+            for (int rb0 = rr; rb0 < BM; rb0 += ROWS * NB) {
+                floatx4 v[NB], u[NB], a1[NB], a2[NB];
+                bool ok[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int r = rb0 + k * ROWS;
+                    ok[k] = (r < BM) && (m0 + r < M);
+                    v[k] = *reinterpret_cast<const floatx4*>(Cs + (r < BM ? r : 0) * LDC + 4 * q);
+                }
+                if (ws) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        if (ok[k]) *reinterpret_cast<floatx4*>(ws + (size_t)(m0 + rb0 + k * ROWS) * d.Cout + co) = v[k];
+                    continue;
+                }
+                if (d.dact_x) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
+                        u[k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
+                    }
+                }
+                if (d.addend) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
+                        if (d.addend_bcast_n) m = m % HoWo;
+                        a1[k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
+                    }
+                }
+                if (d.addend2) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) {
+                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
+                        a2[k] = *reinterpret_cast<const floatx4*>(d.addend2 + m * d.ldadd2 + co);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    floatx4 o = v[k] + bias4;
+                    if (d.dact_x) {
+                        const floatx4 uu = u[k] * ds4 + dt4;
+                        if (d.dact_act == GA_ACT_SILU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(uu[e]); o[e] *= sg * (1.0f + uu[e] * (1.0f - sg)) * ds4[e]; }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] *= act_bwd_fast(uu[e], d.dact_act) * ds4[e];
+                        }
+                    }
+                    if (d.addend) o += a1[k];
+                    if (d.addend2) o += a2[k];
+                    if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)(m0 + rb0 + k * ROWS) * d.ldy + co) = o;
+                }
             }
         }
     } else {
@@ -288,6 +404,18 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ga_conv_d
     }
 }
 
+template <int WM, int WN, int TM, int TN, bool VEC, int PRO>
+static void launch_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
+                        int Ktot, int nkc, int vec_out) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+}
+
 template <int WM, int WN, int TM, int TN>
 static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int vec_out, int splits) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -299,23 +427,14 @@ static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int 
     size_t lds = (size_t)2 * (BM + BN) * LDK * sizeof(float);
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
-    const dim3 grid(tilesM * tilesN, splits), block(256);
+    const dim3 grid(tilesM * tilesN, splits);
+    const int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
     if (vec) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, true>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        if (pro == 0) launch_inst<WM, WN, TM, TN, true, 0>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else if (pro == 1) launch_inst<WM, WN, TM, TN, true, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else launch_inst<WM, WN, TM, TN, true, 2>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, false>), grid, block, lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        launch_inst<WM, WN, TM, TN, false, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
     }
     int rc = check_launch();
     if (rc != GA_OK || splits == 1) return rc;
@@ -336,6 +455,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     if (!d.x || !d.w || !d.y) return GA_E_BADARG;
     if (d.N <= 0 || d.Hi <= 0 || d.Wi <= 0 || d.C1 <= 0 || d.C2 < 0 || d.Ho <= 0 || d.Wo <= 0 || d.Cout <= 0) return GA_E_BADARG;
     if (d.KH <= 0 || d.KW <= 0 || d.sn <= 0 || d.sd <= 0 || d.pad < 0) return GA_E_BADARG;
+    if (d.sd & (d.sd - 1)) return GA_E_UNSUPPORTED;          // transposed stride must be a power of two
     if (d.C2 > 0 && !d.x2) return GA_E_BADARG;
     if ((d.pro_scale == nullptr) != (d.pro_shift == nullptr)) return GA_E_BADARG;
     if (d.dact_x && ((d.dact_scale == nullptr) != (d.dact_shift == nullptr))) return GA_E_BADARG;
