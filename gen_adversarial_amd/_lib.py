@@ -31,7 +31,8 @@ class ConvDesc(C.Structure):
                 ('Ho', i32), ('Wo', i32), ('Cout', i32),
                 ('KH', i32), ('KW', i32), ('sn', i32), ('sd', i32), ('pad', i32),
                 ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
-                ('splits', i32), ('ws', fp), ('ws_floats', C.c_long)]
+                ('splits', i32), ('ws', fp), ('ws_floats', C.c_long),
+                ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('_reserved', C.c_uint)]
 
 
 class DwDesc(C.Structure):

@@ -63,7 +63,11 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
 }
 
 // PRO: 0 = no prologue, 1 = per-channel affine and/or activation, 2 = per-(row,channel) affine (+ activation)
-template <int WM, int WN, int TM, int TN, bool VEC, int PRO>
+// FAST: stride-1 gathers through buffer loads — per output row a byte offset and a tap-validity bitmask are computed
+//       ONCE per workgroup; per K tile a row costs one add + one select (out-of-range lanes get an offset beyond the
+//       buffer and the hardware returns zeros), the tap/channel displacement rides in the scalar offset.  On gfx950
+//       the f32 MFMA runs at the vector-ALU rate, so every VALU instruction saved in the K loop is MFMA time won.
+template <int WM, int WN, int TM, int TN, bool VEC, int PRO, bool FAST>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
                  const int vec_out) {
@@ -100,6 +104,37 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         } else { a_n[i] = -1; a_h0[i] = 0; a_w0[i] = 0; }
     }
 
+    // ---- FAST-path invariants
+    constexpr int INV = 0x7fffffff;                                     // beyond any buffer we accept (< 2 GiB)
+    int baseA[RA], baseA2[RA], baseB[RB];
+    unsigned maskA[RA];
+    __amdgpu_buffer_rsrc_t rsrcX, rsrcX2, rsrcW;
+    if (FAST) {
+        rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
+        rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.C2 > 0 ? d.x2 : d.x), 0, d.C2 > 0 ? d.x2_bytes : d.x_bytes, 0x00020000);
+        rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, d.w_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int pixb = (a_n[i] * d.Hi + a_h0[i]) * d.Wi + a_w0[i];
+            baseA[i] = pixb * d.ldx * 4 + c4 * 16;
+            baseA2[i] = pixb * d.ldx2 * 4 + c4 * 16;
+            unsigned mk = 0;
+            if (a_n[i] >= 0) {
+                for (int kh = 0; kh < d.KH; ++kh)
+                    for (int kw = 0; kw < d.KW; ++kw) {
+                        const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
+                        if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) mk |= 1u << (kh * d.KW + kw);
+                    }
+            }
+            maskA[i] = mk;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int co = n0 + r0 + 32 * i;
+            baseB[i] = co < d.Cout ? (co * Ktot + 4 * c4) * 4 : INV;
+        }
+    }
+
     // ---- tile staging, split in two so that the global loads of tile t+1 are IN FLIGHT while tile t's MFMAs run:
     //      issue_tile(): address math + unconditional loads (out-of-range lanes read a safe address and are zeroed
     //      later: no divergent branch, hence no s_waitcnt, sits between a load and the MFMAs);
@@ -109,13 +144,68 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
     int cur_c = 0;
     const int sd_shift = d.sd > 1 ? 31 - __builtin_clz(d.sd) : 0, sd_mask = d.sd - 1;   // sd is a power of two
 
-    auto issue_tile = [&](const int t) {
-        const int tap = t / nkc, c0 = (t - tap * nkc) * BK;
-        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    // K-tile cursor kept in scalar registers and advanced incrementally (tiles are issued in order): no integer
+    // division in the loop and everything derived from it is provably wave-uniform (buffer descriptors, soffsets).
+    int q_tap = 0, q_chunk = 0, q_kh = 0, q_kw = 0;
+    auto seek_tile = [&](const int t) {
+        q_tap = __builtin_amdgcn_readfirstlane(t / nkc);
+        q_chunk = __builtin_amdgcn_readfirstlane(t - q_tap * nkc);
+        q_kh = __builtin_amdgcn_readfirstlane(q_tap / d.KW);
+        q_kw = q_tap - q_kh * d.KW;
+    };
+
+    auto issue_tile = [&](const int) {
+        const int tap = q_tap, c0 = q_chunk * BK;
+        const int kh = q_kh, kw = q_kw;
+        if (++q_chunk == nkc) { q_chunk = 0; ++q_tap; if (++q_kw == d.KW) { q_kw = 0; ++q_kh; } }
         const int c = c0 + 4 * c4;
         cur_c = c;
         okmask = 0;
-        if (VEC) {
+        if (FAST) {
+            const bool in_x = c0 < d.C1;                                 // uniform: a chunk never straddles the sources
+            const int lim = (in_x ? d.C1 : Ctot) - c0;
+            const bool cval = 4 * c4 < lim;
+            const int delta = (kh * d.Wi + kw) * (in_x ? d.ldx : d.ldx2) * 4;
+            const int soffA = (in_x ? c0 : c0 - d.C1) * 4;
+            const unsigned bit = 1u << tap;
+            if (in_x) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const bool valid = cval & ((maskA[i] & bit) != 0);
+                    const int off = valid ? baseA[i] + delta : INV;
+                    okmask |= (valid ? 1u : 0u) << i;
+                    ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, soffA, 0));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const bool valid = cval & ((maskA[i] & bit) != 0);
+                    const int off = valid ? baseA2[i] + delta : INV;
+                    okmask |= (valid ? 1u : 0u) << i;
+                    ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, soffA, 0));
+                }
+            }
+            const int soffB = (tap * Ctot + c0) * 4;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int off = cval ? baseB[i] : INV;
+                rb[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcW, off, soffB, 0));
+            }
+            if (PRO == 1) {
+                if (d.pro_scale) {
+                    const int pc = (in_x & cval) ? c : 0;
+                    rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
+                    rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
+                }
+            } else if (PRO == 2) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const size_t po = (in_x && ((okmask >> i) & 1u)) ? (size_t)a_n[i] * d.C1 + c : 0;
+                    rs[i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
+                    rt[i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
+                }
+            }
+        } else if (VEC) {
             const bool first = c < d.C1;
             const bool cok = c < Ctot;
             const float* src[RA];
@@ -205,7 +295,30 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-        if (VEC) {
+        if (FAST) {
+            const bool first = cur_c < d.C1;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                floatx4 v = ra[i];
+                if (PRO != 0) {
+                    floatx4 pv = v;
+                    if (PRO == 2) pv = pv * rs[i] + rt[i];
+                    else if (d.pro_scale) pv = pv * rs[0] + rt[0];
+                    if (d.pro_act == GA_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
+                    } else if (d.pro_act != GA_ACT_NONE) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] = act_fwd_fast(pv[e], d.pro_act);
+                    }
+                    v = first ? pv : v;
+                    v = (okmask >> i) & 1u ? v : zero;                  // act(shift) != 0 on padded taps
+                }
+                *reinterpret_cast<floatx4*>(Ab + (r0 + 32 * i) * LDK + 4 * c4) = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) *reinterpret_cast<floatx4*>(Bb + (r0 + 32 * i) * LDK + 4 * c4) = rb[i];
+        } else if (VEC) {
             const bool first = cur_c < d.C1;
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
@@ -254,6 +367,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
 
     const int lrow = lane & 31, lh = lane >> 5;
     if (t_begin < t_end) {
+        seek_tile(t_begin);
         issue_tile(t_begin);
         finish_tile(0);
     }
@@ -404,16 +518,16 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ga_conv_d
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool VEC, int PRO>
+template <int WM, int WN, int TM, int TN, bool VEC, int PRO, bool FAST>
 static void launch_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                         int Ktot, int nkc, int vec_out) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -429,12 +543,18 @@ static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int 
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
     const int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
-    if (vec) {
-        if (pro == 0) launch_inst<WM, WN, TM, TN, true, 0>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
-        else if (pro == 1) launch_inst<WM, WN, TM, TN, true, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
-        else launch_inst<WM, WN, TM, TN, true, 2>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    const bool fast = vec && d.sd == 1 && (d.C2 == 0 || d.C1 % BK == 0) && d.KH * d.KW <= 32 &&
+                      d.x_bytes > 0 && d.w_bytes > 0 && (d.C2 == 0 || d.x2_bytes > 0);
+    if (fast) {
+        if (pro == 0) launch_inst<WM, WN, TM, TN, true, 0, true>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else if (pro == 1) launch_inst<WM, WN, TM, TN, true, 1, true>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else launch_inst<WM, WN, TM, TN, true, 2, true>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    } else if (vec) {
+        if (pro == 0) launch_inst<WM, WN, TM, TN, true, 0, false>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else if (pro == 1) launch_inst<WM, WN, TM, TN, true, 1, false>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        else launch_inst<WM, WN, TM, TN, true, 2, false>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
     } else {
-        launch_inst<WM, WN, TM, TN, false, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+        launch_inst<WM, WN, TM, TN, false, 1, false>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
     }
     int rc = check_launch();
     if (rc != GA_OK || splits == 1) return rc;
@@ -496,11 +616,20 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
             else tile = 3;
         }
     }
+    // buffer extents for the FAST loader (0 = tensor too large for 31-bit byte offsets -> generic loader)
+    ga_conv_desc k = d;
+    const long xb = ((long)d.N * d.Hi * d.Wi - 1) * d.ldx * 4 + (long)d.C1 * 4;
+    const long x2b = d.C2 > 0 ? ((long)d.N * d.Hi * d.Wi - 1) * d.ldx2 * 4 + (long)d.C2 * 4 : 0;
+    const long wb = (long)d.Cout * d.KH * d.KW * (d.C1 + d.C2) * 4;
+    const long lim = 0x7fffff00L;
+    k.x_bytes = xb < lim ? (unsigned)xb : 0;
+    k.x2_bytes = x2b < lim ? (unsigned)x2b : 0;
+    k.w_bytes = wb < lim ? (unsigned)wb : 0;
     switch (tile) {
-        case 1: return launch_conv<2, 2, 2, 2>(d, stream, vec, vec_out, splits);
-        case 2: return launch_conv<4, 1, 1, 2>(d, stream, vec, vec_out, splits);
-        case 3: return launch_conv<2, 2, 1, 1>(d, stream, vec, vec_out, splits);
-        case 4: return launch_conv<4, 1, 1, 1>(d, stream, vec, vec_out, splits);
+        case 1: return launch_conv<2, 2, 2, 2>(k, stream, vec, vec_out, splits);
+        case 2: return launch_conv<4, 1, 1, 2>(k, stream, vec, vec_out, splits);
+        case 3: return launch_conv<2, 2, 1, 1>(k, stream, vec, vec_out, splits);
+        case 4: return launch_conv<4, 1, 1, 1>(k, stream, vec, vec_out, splits);
         default: return GA_E_UNSUPPORTED;
     }
 }

@@ -74,6 +74,8 @@ typedef struct ga_conv_desc {
     int splits;                            /* split-K factor (<=1: none); needs ws */
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
     long ws_floats;
+    unsigned x_bytes, x2_bytes, w_bytes;   /* filled in by ga_conv2d (buffer extents); callers leave them 0 */
+    unsigned _reserved;
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
