@@ -32,7 +32,8 @@ class ConvDesc(C.Structure):
                 ('KH', i32), ('KW', i32), ('sn', i32), ('sd', i32), ('pad', i32),
                 ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
                 ('splits', i32), ('ws', fp), ('ws_floats', C.c_long),
-                ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('_reserved', C.c_uint)]
+                ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('_reserved', C.c_uint),
+                ('w_hi', fp), ('w_lo', fp)]
 
 
 class DwDesc(C.Structure):
@@ -48,7 +49,8 @@ class ReduceDesc(C.Structure):
 class SeExciteDesc(C.Structure):
     _fields_ = [('m', fp), ('w1', fp), ('b1', fp), ('w2', fp), ('b2', fp), ('hid', fp), ('gate', fp),
                 ('dgate', fp), ('pro_scale', fp), ('pro_shift', fp),
-                ('N', i32), ('C', i32), ('Hd', i32), ('P', i32), ('res_scale', f32), ('backward', i32)]
+                ('N', i32), ('C', i32), ('Hd', i32), ('P', i32), ('res_scale', f32), ('backward', i32),
+                ('t', fp), ('dout', fp)]
 
 
 class SeApplyDesc(C.Structure):
@@ -106,7 +108,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile',
+           'ga_plan_profile', 'ga_split_bf16',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -131,6 +133,8 @@ def _load():
     lib.ga_plan_time.restype = C.c_int
     lib.ga_plan_profile.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(f32)]
     lib.ga_plan_profile.restype = C.c_int
+    lib.ga_split_bf16.argtypes = [fp, fp, fp, C.c_long, C.c_void_p]
+    lib.ga_split_bf16.restype = C.c_int
     lib.ga_last_hip_error.restype = C.c_char_p
     lib.ga_abi_version.restype = C.c_int
     lib.ga_sizeof_op.restype = C.c_ulong

@@ -1,0 +1,319 @@
+// conv_bf3 — the implicit-GEMM convolution of conv_mfma.hip on the bf16 matrix cores with fp32-class accuracy.
+//
+// On gfx950 the f32-input MFMA runs at the vector-ALU rate (64 FLOP/clk/SIMD); the bf16 MFMA runs 16x faster.  Every
+// fp32 operand x is split as x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-16 |x|, and
+//     a*b  ~=  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi        (three v_mfma_f32_32x32x16_bf16, fp32 accumulation)
+// which keeps ~16 mantissa bits per product (relative error ~2e-5 per product, averaging down over K) — two orders
+// of magnitude inside the path's 1e-3 parity bar — at 16/3 of the f32-MFMA rate.
+//   * activations: split in registers by the loader, after the prologue (affine / SiLU / ELU / ReLU), right before
+//     the LDS write: v_cvt_pk_bf16_f32 x2, shift back, subtract, v_cvt_pk again (12 VALU per float4; the bf16 matrix
+//     pipe runs beside the VALU, unlike the f32 MFMA);
+//   * weights: split once at load time on the host into two bf16 [Cout][K] arrays (w_hi, w_lo);
+//   * LDS: four bf16 tiles per stage (A_hi, A_lo, B_hi, B_lo), rows of 32 k + 8 pad = 80 B: the 16-B fragment reads
+//     of a 16-lane group fall on 16 distinct slots of the 256-B bank row (80*r mod 256 is a bijection on r < 16);
+//   * fragments: lane (r = lane&31, h = lane>>5) reads the 8 bf16 A[r][8h..8h+7] / B[8h..8h+7][r] of a 16-deep k step
+//     as ONE ds_read_b128 — exactly the operand layout of v_mfma_f32_32x32x16_bf16;
+//   * everything else (gather by buffer loads with per-row offsets and tap masks, scalar K cursor, register
+//     prefetch across the MFMAs, double-buffered LDS, LDS-transposed vector epilogue, split-K) is shared with the
+//     fp32 kernel.  Shapes this kernel does not take (stride-2 transposes, channel counts not multiple of 8, the
+//     3-channel image) run on the exact fp32-MFMA kernel.
+#include "ga_common.h"
+#include "conv_epilogue.h"
+
+namespace ga {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK3 = 32;     // k per LDS stage
+constexpr int LDB = 40;     // bf16 elements per LDS row (32 + 8 pad = 80 B)
+
+template <int WM, int WN, int TM, int TN, int PRO>
+__global__ void __launch_bounds__(256)
+conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
+                const int vec_out) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int RA = BM / 32;
+    constexpr int RB = BN >= 64 ? BN / 64 : 1;
+    constexpr int STAGE = (2 * BM + 2 * BN) * LDB;          // bf16 elements per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* lds = reinterpret_cast<__bf16*>(smem);
+
+    int bid;
+    {
+        const int nb = gridDim.x, orig = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = orig & 7, k = orig >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int c4 = tid & 7, r0 = tid >> 3;                  // A staging: 8 channel-quads x 32 rows
+    const int k8 = tid & 3, rb0 = tid >> 2;                 // B staging: 4 k-octets x 64 rows
+
+    const int HoWo = d.Ho * d.Wo;
+    constexpr int INV = 0x7fffffff;
+    int a_n[RA], baseA[RA], baseA2[RA], baseB[RB];
+    unsigned maskA[RA];
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.C2 > 0 ? d.x2 : d.x), 0,
+                                                                             d.C2 > 0 ? d.x2_bytes : d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcWh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_hi), 0, d.w_bytes / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcWl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_lo), 0, d.w_bytes / 2, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        unsigned mk = 0;
+        int n = -1, h0 = 0, w0 = 0;
+        if (m < M) {
+            n = m / HoWo;
+            const int rem = m - n * HoWo, ho = rem / d.Wo, wo = rem - ho * d.Wo;
+            h0 = ho * d.sn - d.pad; w0 = wo * d.sn - d.pad;
+            for (int kh = 0; kh < d.KH; ++kh)
+                for (int kw = 0; kw < d.KW; ++kw) {
+                    const int hi = h0 + kh, wi = w0 + kw;
+                    if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) mk |= 1u << (kh * d.KW + kw);
+                }
+        }
+        a_n[i] = n;
+        maskA[i] = mk;
+        const int pixb = (n * d.Hi + h0) * d.Wi + w0;
+        baseA[i] = pixb * d.ldx * 4 + c4 * 16;
+        baseA2[i] = pixb * d.ldx2 * 4 + c4 * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = rb0 + 64 * i;
+        const int co = n0 + row;
+        baseB[i] = (row < BN && co < d.Cout) ? (co * Ktot + 8 * k8) * 2 : INV;
+    }
+
+    floatx4 ra[RA], rs[PRO == 2 ? RA : 1], rt[PRO == 2 ? RA : 1];
+    uintx4 rbh[RB], rbl[RB];
+    unsigned okmask = 0;
+    int cur_c = 0;
+
+    int q_tap = 0, q_chunk = 0, q_kh = 0, q_kw = 0;
+    auto seek_tile = [&](const int t) {
+        q_tap = __builtin_amdgcn_readfirstlane(t / nkc);
+        q_chunk = __builtin_amdgcn_readfirstlane(t - q_tap * nkc);
+        q_kh = __builtin_amdgcn_readfirstlane(q_tap / d.KW);
+        q_kw = q_tap - q_kh * d.KW;
+    };
+
+    auto issue_tile = [&]() {
+        const int tap = q_tap, c0 = q_chunk * BK3;
+        const int kh = q_kh, kw = q_kw;
+        if (++q_chunk == nkc) { q_chunk = 0; ++q_tap; if (++q_kw == d.KW) { q_kw = 0; ++q_kh; } }
+        const int c = c0 + 4 * c4;
+        cur_c = c;
+        okmask = 0;
+        const bool in_x = c0 < d.C1;
+        const int lim = (in_x ? d.C1 : Ctot) - c0;
+        const bool cval = 4 * c4 < lim;
+        const int delta = (kh * d.Wi + kw) * (in_x ? d.ldx : d.ldx2) * 4;
+        const int soffA = (in_x ? c0 : c0 - d.C1) * 4;
+        const unsigned bit = 1u << tap;
+        if (in_x) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const bool valid = cval & ((maskA[i] & bit) != 0);
+                const int off = valid ? baseA[i] + delta : INV;
+                okmask |= (valid ? 1u : 0u) << i;
+                ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, soffA, 0));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const bool valid = cval & ((maskA[i] & bit) != 0);
+                const int off = valid ? baseA2[i] + delta : INV;
+                okmask |= (valid ? 1u : 0u) << i;
+                ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, soffA, 0));
+            }
+        }
+        const int soffB = (tap * Ctot + c0) * 2;
+        const bool bval = c0 + 8 * k8 < Ctot;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int off = bval ? baseB[i] : INV;
+            rbh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWh, off, soffB, 0);
+            rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, off, soffB, 0);
+        }
+        if (PRO == 1) {
+            if (d.pro_scale) {
+                const int pc = (in_x & cval) ? c : 0;
+                rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
+                rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
+            }
+        } else if (PRO == 2) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const size_t po = (in_x && ((okmask >> i) & 1u)) ? (size_t)a_n[i] * d.C1 + c : 0;
+                rs[i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
+                rt[i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
+            }
+        }
+    };
+
+    auto finish_tile = [&](const int buf) {
+        __bf16* Ah = lds + buf * STAGE;
+        __bf16* Al = Ah + BM * LDB;
+        __bf16* Bh = Al + BM * LDB;
+        __bf16* Bl = Bh + BN * LDB;
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+        const bool first = cur_c < d.C1;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            floatx4 v = ra[i];
+            if (PRO != 0) {
+                floatx4 pv = v;
+                if (PRO == 2) pv = pv * rs[i] + rt[i];
+                else if (d.pro_scale) pv = pv * rs[0] + rt[0];
+                if (d.pro_act == GA_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
+                } else if (d.pro_act != GA_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = act_fwd_fast(pv[e], d.pro_act);
+                }
+                v = first ? pv : v;
+                v = (okmask >> i) & 1u ? v : zero;
+            }
+            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
+            const int o = (r0 + 32 * i) * LDB + 4 * c4;
+            *reinterpret_cast<bf16x4*>(Ah + o) = hi;
+            *reinterpret_cast<bf16x4*>(Al + o) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = rb0 + 64 * i;
+            if (row < BN) {
+                *reinterpret_cast<uintx4*>(Bh + row * LDB + 8 * k8) = rbh[i];
+                *reinterpret_cast<uintx4*>(Bl + row * LDB + 8 * k8) = rbl[i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int T = d.KH * d.KW * nkc;
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int tper = (T + splits - 1) / splits;
+    const int t_begin = split * tper;
+    const int t_end = min(T, t_begin + tper);
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    if (t_begin < t_end) {
+        seek_tile(t_begin);
+        issue_tile();
+        finish_tile(0);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) issue_tile();
+        const __bf16* Ah = lds + buf * STAGE + (wm * TM * 32 + lrow) * LDB + 8 * lh;
+        const __bf16* Al = Ah + BM * LDB;
+        const __bf16* Bh = lds + buf * STAGE + 2 * BM * LDB + (wn * TN * 32 + lrow) * LDB + 8 * lh;
+        const __bf16* Bl = Bh + BN * LDB;
+#pragma unroll
+        for (int ks = 0; ks < BK3 / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ah + i * 32 * LDB + ks * 16);
+                al[i] = *reinterpret_cast<const bf16x8*>(Al + i * 32 * LDB + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 32 * LDB + ks * 16);
+                bl[j] = *reinterpret_cast<const bf16x8*>(Bl + j * 32 * LDB + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (t + 1 < t_end) finish_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
+}
+
+template <int WM, int WN, int TM, int TN, int PRO>
+static void launch_bf3_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
+                            int Ktot, int nkc, int vec_out) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, PRO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, PRO>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_bf3(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int M = d.N * d.Ho * d.Wo;
+    const int Ctot = d.C1 + d.C2;
+    const int Ktot = d.KH * d.KW * Ctot;
+    const int nkc = (Ctot + BK3 - 1) / BK3;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
+    size_t lds = (size_t)2 * (2 * BM + 2 * BN) * LDB * 2;
+    const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    if (lds_c > lds) lds = lds_c;
+    const dim3 grid(tilesM * tilesN, splits);
+    const int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
+    if (pro == 0) launch_bf3_inst<WM, WN, TM, TN, 0>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    else if (pro == 1) launch_bf3_inst<WM, WN, TM, TN, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    else launch_bf3_inst<WM, WN, TM, TN, 2>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    return check_launch();
+}
+
+// called by ga_conv2d (conv_mfma.hip) once the descriptor has been validated and the buffer extents filled in
+int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
+    switch (tile) {
+        case 1: return launch_bf3<2, 2, 2, 2>(d, stream, vec_out, splits);
+        case 2: return launch_bf3<4, 1, 1, 2>(d, stream, vec_out, splits);
+        case 3: return launch_bf3<2, 2, 1, 1>(d, stream, vec_out, splits);
+        case 4: return launch_bf3<4, 1, 1, 1>(d, stream, vec_out, splits);
+        default: return GA_E_UNSUPPORTED;
+    }
+}
+
+// host helper exported for weight preparation: w (fp32, n elements) -> hi, lo (bf16 bit patterns)
+__global__ void split_bf16_kernel(const float* w, __bf16* hi, __bf16* lo, const long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = w[i];
+        const __bf16 h = (__bf16)v;
+        hi[i] = h;
+        lo[i] = (__bf16)(v - (float)h);
+    }
+}
+
+}  // namespace ga
+
+extern "C" int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream) {
+    if (!w || !hi || !lo || n <= 0) return GA_E_BADARG;
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ga::split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16*)hi, (__bf16*)lo, n);
+    return ga::check_launch();
+}

@@ -19,48 +19,12 @@
 //     a caller-provided workspace and a second kernel sums them in a fixed order and applies the epilogue.
 //   * blockIdx is remapped so that consecutive logical tiles (which share the A panel) run on one XCD's L2.
 #include "ga_common.h"
+#include "conv_epilogue.h"
 
 namespace ga {
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
-
-// epilogue on 4 consecutive channels of one output pixel (vector form)
-__device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, const int co, floatx4 v, const int HoWo) {
-    if (d.bias) v += *reinterpret_cast<const floatx4*>(d.bias + co);
-    if (d.dact_x) {
-        floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)m * d.lddact + co);
-        floatx4 ds = {1.f, 1.f, 1.f, 1.f};
-        if (d.dact_scale) {
-            ds = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
-            u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + co);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
-    }
-    if (d.addend) {
-        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
-        v += *reinterpret_cast<const floatx4*>(d.addend + am * d.ldadd + co);
-    }
-    if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + (size_t)m * d.ldadd2 + co);
-    *reinterpret_cast<floatx4*>(d.y + (size_t)m * d.ldy + co) = v;
-}
-
-__device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, const int co, float v, const int HoWo) {
-    if (d.bias) v += d.bias[co];
-    if (d.dact_x) {
-        float ds = 1.f, db = 0.f;
-        if (d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
-        const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
-        v *= act_bwd_fast(u, d.dact_act) * ds;
-    }
-    if (d.addend) {
-        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
-        v += d.addend[am * d.ldadd + co];
-    }
-    if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
-    d.y[(size_t)m * d.ldy + co] = v;
-}
 
 // PRO: 0 = no prologue, 1 = per-channel affine and/or activation, 2 = per-(row,channel) affine (+ activation)
 // FAST: stride-1 gathers through buffer loads — per output row a byte offset and a tap-validity bitmask are computed
@@ -396,105 +360,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
-    float* ws = splits > 1 ? d.ws + (size_t)split * M * d.Cout : nullptr;
-    if (vec_out) {
-        float* Cs = smem;                                   // [BM][LDC], the K loop's buffers are free now
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Cs[(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
-        __syncthreads();
-        constexpr int QL = BN / 4;                          // channel-quads per row
-        constexpr int ROWS = 256 / QL;                      // rows per pass
-        const int q = tid % QL, rr = tid / QL;
-        const int co = n0 + 4 * q;
-        if (co < d.Cout) {
-            constexpr int NB = (BM / ROWS) < 4 ? (BM / ROWS) : 4;      // rows handled together: loads first, math after
-            floatx4 bias4 = {0.f, 0.f, 0.f, 0.f}, ds4 = {1.f, 1.f, 1.f, 1.f}, dt4 = {0.f, 0.f, 0.f, 0.f};
-            if (!ws) {
-                if (d.bias) bias4 = *reinterpret_cast<const floatx4*>(d.bias + co);
-                if (d.dact_x && d.dact_scale) {
-                    ds4 = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
-                    dt4 = *reinterpret_cast<const floatx4*>(d.dact_shift + co);
-                }
-            }
-            for (int rb0 = rr; rb0 < BM; rb0 += ROWS * NB) {
-                floatx4 v[NB], u[NB], a1[NB], a2[NB];
-                bool ok[NB];
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    const int r = rb0 + k * ROWS;
-                    ok[k] = (r < BM) && (m0 + r < M);
-                    v[k] = *reinterpret_cast<const floatx4*>(Cs + (r < BM ? r : 0) * LDC + 4 * q);
-                }
-                if (ws) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k)
-                        if (ok[k]) *reinterpret_cast<floatx4*>(ws + (size_t)(m0 + rb0 + k * ROWS) * d.Cout + co) = v[k];
-                    continue;
-                }
-                if (d.dact_x) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
-                        u[k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
-                    }
-                }
-                if (d.addend) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
-                        if (d.addend_bcast_n) m = m % HoWo;
-                        a1[k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
-                    }
-                }
-                if (d.addend2) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
-                        a2[k] = *reinterpret_cast<const floatx4*>(d.addend2 + m * d.ldadd2 + co);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NB; ++k) {
-                    floatx4 o = v[k] + bias4;
-                    if (d.dact_x) {
-                        const floatx4 uu = u[k] * ds4 + dt4;
-                        if (d.dact_act == GA_ACT_SILU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(uu[e]); o[e] *= sg * (1.0f + uu[e] * (1.0f - sg)) * ds4[e]; }
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] *= act_bwd_fast(uu[e], d.dact_act) * ds4[e];
-                        }
-                    }
-                    if (d.addend) o += a1[k];
-                    if (d.addend2) o += a2[k];
-                    if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)(m0 + rb0 + k * ROWS) * d.ldy + co) = o;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn * TN * 32 + j * 32 + lrow;
-            if (co >= d.Cout) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= M) continue;
-                    if (ws) ws[(size_t)m * d.Cout + co] = acc[i][j][r];
-                    else epilogue1(d, m, co, acc[i][j][r], HoWo);
-                }
-            }
-        }
-    }
+    conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
 }
 
 // sums the split-K partial tiles in split order (bitwise reproducible) and applies the epilogue
@@ -556,14 +422,10 @@ static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int 
     } else {
         launch_inst<WM, WN, TM, TN, false, 1, false>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
     }
-    int rc = check_launch();
-    if (rc != GA_OK || splits == 1) return rc;
-    long items = (long)M * d.Cout / (vec_out ? 4 : 1);
-    long blocks = (items + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, M, splits, vec_out);
     return check_launch();
 }
+
+int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits);   // conv_bf3.hip
 
 }  // namespace ga
 
@@ -625,11 +487,26 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     k.x_bytes = xb < lim ? (unsigned)xb : 0;
     k.x2_bytes = x2b < lim ? (unsigned)x2b : 0;
     k.w_bytes = wb < lim ? (unsigned)wb : 0;
-    switch (tile) {
-        case 1: return launch_conv<2, 2, 2, 2>(k, stream, vec, vec_out, splits);
-        case 2: return launch_conv<4, 1, 1, 2>(k, stream, vec, vec_out, splits);
-        case 3: return launch_conv<2, 2, 1, 1>(k, stream, vec, vec_out, splits);
-        case 4: return launch_conv<4, 1, 1, 1>(k, stream, vec, vec_out, splits);
-        default: return GA_E_UNSUPPORTED;
+    const int Ctot = d.C1 + d.C2;
+    const bool bf3 = d.w_hi && d.w_lo && vec && d.sd == 1 && (d.C2 == 0 || d.C1 % 32 == 0) && (Ctot % 8 == 0) &&
+                     d.KH * d.KW <= 32 && k.x_bytes > 0 && k.w_bytes > 0 && (d.C2 == 0 || k.x2_bytes > 0) &&
+                     aligned16(d.w_hi) && aligned16(d.w_lo);
+    int rc;
+    if (bf3) {
+        rc = conv_bf3_dispatch(k, stream, tile, vec_out, splits);
+    } else {
+        switch (tile) {
+            case 1: rc = launch_conv<2, 2, 2, 2>(k, stream, vec, vec_out, splits); break;
+            case 2: rc = launch_conv<4, 1, 1, 2>(k, stream, vec, vec_out, splits); break;
+            case 3: rc = launch_conv<2, 2, 1, 1>(k, stream, vec, vec_out, splits); break;
+            case 4: rc = launch_conv<4, 1, 1, 1>(k, stream, vec, vec_out, splits); break;
+            default: return GA_E_UNSUPPORTED;
+        }
     }
+    if (rc != GA_OK || splits == 1) return rc;
+    long items = M * d.Cout / (vec_out ? 4 : 1);
+    long blocks = (items + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, k, (int)M, splits, vec_out);
+    return check_launch();
 }

@@ -41,10 +41,37 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
     extern __shared__ float sm[];
     float* s_in = sm;            // C
     float* s_hid = sm + d.C;     // Hd
+    float* s_part = sm + d.C + d.Hd;   // fused reduction: [PL][C]
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!d.backward) {
-        for (int c = tid; c < d.C; c += 256) s_in[c] = d.m[(size_t)n * d.C + c];
+    if (d.t) {
+        // fused squeeze / d(gate): channel-quad lanes x pixel lanes, fixed summation order
+        const int C4 = d.C >> 2, PL = 256 / C4;
+        const int q = tid % C4, pl = tid / C4;
+        if (pl < PL) {
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* a = d.t + (size_t)n * d.P * d.C + 4 * q;
+            const float* b = d.backward ? d.dout + (size_t)n * d.P * d.C + 4 * q : nullptr;
+            for (int p = pl; p < d.P; p += PL) {
+                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+                acc += v;
+            }
+            *reinterpret_cast<floatx4*>(s_part + pl * d.C + 4 * q) = acc;
+        }
         __syncthreads();
+        const float sc = d.backward ? d.res_scale : 1.0f / (float)d.P;
+        for (int c = tid; c < d.C; c += 256) {
+            float s = s_part[c];
+            for (int k = 1; k < PL; ++k) s += s_part[k * d.C + c];
+            s_in[c] = s * sc;
+        }
+        __syncthreads();
+    }
+    if (!d.backward) {
+        if (!d.t) {
+            for (int c = tid; c < d.C; c += 256) s_in[c] = d.m[(size_t)n * d.C + c];
+            __syncthreads();
+        }
         for (int j = wave; j < d.Hd; j += 4) {
             float acc = 0.f;
             for (int c = lane; c < d.C; c += 64) acc += d.w1[(size_t)j * d.C + c] * s_in[c];
@@ -62,7 +89,8 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
         // ds[c] = dgate * gate * (1 - gate)
         for (int c = tid; c < d.C; c += 256) {
             const float g = d.gate[(size_t)n * d.C + c];
-            s_in[c] = d.dgate[(size_t)n * d.C + c] * g * (1.f - g);
+            const float dg = d.t ? s_in[c] : d.dgate[(size_t)n * d.C + c];
+            s_in[c] = dg * g * (1.f - g);
         }
         __syncthreads();
         for (int j = wave; j < d.Hd; j += 4) {
@@ -354,9 +382,15 @@ extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
 
 extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
     if (!d || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->hid || !d->gate || d->N <= 0 || d->C <= 0 || d->Hd <= 0) return GA_E_BADARG;
-    if (!d->backward && !d->m) return GA_E_BADARG;
-    if (d->backward && (!d->dgate || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
-    const size_t lds = (size_t)(d->C + d->Hd) * sizeof(float);
+    if (!d->backward && !d->m && !d->t) return GA_E_BADARG;
+    if (d->backward && ((!d->dgate && !d->t) || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
+    size_t lds = (size_t)(d->C + d->Hd) * sizeof(float);
+    if (d->t) {
+        if (d->P <= 0 || (d->backward && !d->dout)) return GA_E_BADARG;
+        if (d->C % 4 || d->C > 1024) return GA_E_UNSUPPORTED;
+        if (!aligned16(d->t) || (d->dout && !aligned16(d->dout))) return GA_E_ALIGN;
+        lds += (size_t)(256 / (d->C / 4)) * d->C * sizeof(float);
+    }
     if (lds > 64 * 1024) return GA_E_UNSUPPORTED;
     hipLaunchKernelGGL(se_excite_kernel, dim3(d->N), dim3(256), lds, (hipStream_t)s, *d);
     return check_launch();

@@ -42,7 +42,7 @@ def tune_cache() -> dict:
 
 
 def conv_key(d) -> str:
-    return '_'.join(str(int(v)) for v in (
+    return ('b3_' if d.w_hi else '') + '_'.join(str(int(v)) for v in (
         d.N * d.Ho * d.Wo, d.Cout, d.C1, d.C2, d.KH, d.sn, d.sd, d.Hi, d.pro_act, bool(d.pro_scale), d.pro_per_row,
         bool(d.dact_x), d.dact_act, bool(d.addend), bool(d.addend2), d.addend_bcast_n))
 
@@ -57,7 +57,18 @@ class WeightStore:
     def __init__(self, device):
         self.device = torch.device(device)
         self.cache: Dict[str, dict] = {}
+        self.splits: Dict[int, tuple] = {}
         self.bytes = 0
+
+    def split(self, w: torch.Tensor):
+        """bf16 (hi, lo) pair of a device weight tensor, hi = bf16(w), lo = bf16(w - hi); made once per tensor."""
+        k = w.data_ptr()
+        if k not in self.splits:
+            hi = w.to(torch.bfloat16)
+            lo = (w - hi.float()).to(torch.bfloat16)
+            self.splits[k] = (hi.contiguous(), lo.contiguous(), w)
+            self.bytes += 4 * w.numel()
+        return self.splits[k][0], self.splits[k][1]
 
     def get(self, key: str, fn):
         if key not in self.cache:
@@ -88,7 +99,7 @@ class Engine:
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
-                 store: Optional[WeightStore] = None):
+                 store: Optional[WeightStore] = None, precision: str = 'bf16x3'):
         if rows % rep:
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.device = torch.device(device)
@@ -96,6 +107,9 @@ class Engine:
         if self.device.type != 'cuda' and not dry_run:
             raise RuntimeError('the HIP engine needs a GPU device; there is no CPU fallback '
                                '(dry_run=True only builds and validates the plans)')
+        if precision not in ('fp32', 'bf16x3'):
+            raise ValueError("precision must be 'fp32' (exact f32 MFMA) or 'bf16x3' (3 bf16 MFMAs per product)")
+        self.precision = precision
         self.store = store if store is not None else WeightStore(self.device)
         self.has_nvae = nvae_sd is not None
         self.spec: Optional[NVAESpec] = build_spec(nvae_cfg, resolution) if self.has_nvae else None
@@ -148,6 +162,9 @@ class Engine:
         if x2 is not None:
             d.x2, d.ldx2, d.C2 = _ptr(x2), x2.shape[3], x2.shape[3]
         d.w, d.bias = _ptr(w), _ptr(bias)
+        if self.precision == 'bf16x3' and not self.dry_run:
+            hi, lo = self.store.split(w)
+            d.w_hi, d.w_lo = _ptr(hi), _ptr(lo)
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
         No, Ho, Wo, Cy = y.shape
         d.y, d.ldy = _ptr(y), Cy
@@ -186,32 +203,26 @@ class Engine:
         """squeeze + excite; returns (gate, hid) buffers."""
         n, c = t.n, t.c
         hd = wts['se_w1'].shape[0]
-        m = self.alloc((n, c))
         hid = self.alloc((n, hd))
         gate = self.alloc((n, c))
-        r = L.ReduceDesc()
-        r.a, r.out, r.N, r.P, r.C, r.scale = _ptr(t.t), _ptr(m), n, P, c, 1.0 / P
-        self.fwd.add(r, f'{name}.squeeze')
         e = L.SeExciteDesc()
-        e.m, e.w1, e.b1, e.w2, e.b2 = _ptr(m), _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
+        e.t = _ptr(t.t)                                     # fused squeeze + excite (one workgroup per row)
+        e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
         e.hid, e.gate, e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = _ptr(hid), _ptr(gate), n, c, hd, P, RES_SCALE, 0
-        self.fwd.add(e, f'{name}.excite')
+        self.fwd.add(e, f'{name}.se_gate')
         return gate, hid
 
     def se_backward(self, name, dout: torch.Tensor, t: Act, wts, gate, hid, P):
         """emits d(gate) reduction + excite backward; returns the per-row prologue (scale, shift) for the next GEMM."""
         n, c = t.n, t.c
-        dgate = self.scratch((n, c), f'dgate{c}')
         ps = self.scratch((n, c), f'ps{c}')
         pb = self.scratch((n, c), f'pb{c}')
-        r = L.ReduceDesc()
-        r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(dout), _ptr(t.t), _ptr(dgate), n, P, c, RES_SCALE
-        self.bwd.add(r, f'{name}.dgate')
         e = L.SeExciteDesc()
+        e.t, e.dout = _ptr(t.t), _ptr(dout)                 # fused d(gate) reduction + excite backward
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
-        e.hid, e.gate, e.dgate, e.pro_scale, e.pro_shift = _ptr(hid), _ptr(gate), _ptr(dgate), _ptr(ps), _ptr(pb)
+        e.hid, e.gate, e.pro_scale, e.pro_shift = _ptr(hid), _ptr(gate), _ptr(ps), _ptr(pb)
         e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = n, c, wts['se_w1'].shape[0], P, RES_SCALE, 1
-        self.bwd.add(e, f'{name}.excite_bwd')
+        self.bwd.add(e, f'{name}.se_gate_bwd')
         return ps, pb
 
     def scratch(self, shape, key) -> torch.Tensor:

@@ -76,6 +76,9 @@ typedef struct ga_conv_desc {
     long ws_floats;
     unsigned x_bytes, x2_bytes, w_bytes;   /* filled in by ga_conv2d (buffer extents); callers leave them 0 */
     unsigned _reserved;
+    const void* w_hi;                      /* optional: w split as bf16 hi + lo, both [Cout][KH*KW*(C1+C2)] (ga_split_bf16). */
+    const void* w_lo;                      /* When given and the shape allows, the contraction runs as 3 bf16 MFMAs per
+                                              product on the bf16 matrix cores (~2e-5 relative), else exact fp32 MFMA. */
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
@@ -119,6 +122,10 @@ typedef struct ga_se_excite_desc {
     const float* dgate;    /* bwd only */
     float* pro_scale; float* pro_shift;  /* bwd only, [N,C] */
     int N, C, Hd, P; float res_scale; int backward;
+    /* fused form: when t != NULL the kernel first reduces over the P pixels itself (one workgroup per row):
+     *   forward  m[c]     = (1/P) sum_p t[n,p,c]                       (m input ignored)
+     *   backward dgate[c] = res_scale * sum_p dout[n,p,c] * t[n,p,c]   (dgate input ignored)            */
+    const float* t; const float* dout;
 } ga_se_excite_desc;
 int ga_se_excite(const ga_se_excite_desc* d, void* stream);
 
@@ -191,6 +198,9 @@ typedef struct ga_image_io_desc {
     int N, C, H, W; int rep; int backward;
 } ga_image_io_desc;
 int ga_image_io(const ga_image_io_desc* d, void* stream);
+
+/* w[n] fp32 -> hi[n], lo[n] bf16 with hi = bf16(w), lo = bf16(w - hi) (weight preparation for w_hi / w_lo) */
+int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream);
 
 /* y = alpha*x + beta*y over n floats */
 int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* stream);

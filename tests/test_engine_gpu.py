@@ -32,14 +32,17 @@ def _err(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
 
 
-def _setup(g, rows, rep):
+PRECISIONS = [('fp32', TOL), ('bf16x3', TOL_SPEC)]
+
+
+def _setup(g, rows, rep, precision='fp32'):
     cfg, res = golden_cfg(g)
     sd = init_nvae_state_dict(cfg, res, int(g['nvae_seed']))
     vspec = build_vgg_spec(int(g['n_classes']), int(g['width_div']))
     vsd = init_vgg_state_dict(int(g['n_classes']), int(g['width_div']), int(g['vgg_seed']))
     alphas = [float(a) * float(g['attenuation']) for a in g['alphas']]
     eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, temperature=0.6,
-                 noise_eps=float(g['noise_eps']), device=DEV)
+                 noise_eps=float(g['noise_eps']), device=DEV, precision=precision)
     return eng
 
 
@@ -50,11 +53,12 @@ def _load_noise(eng, noise, eps):
         eng.noise_coef.copy_(eps / n.flatten(1).norm(dim=1))
 
 
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
 @pytest.mark.parametrize('name', CASES)
-def test_defender_matches_reference_golden(name, golden_cases):
+def test_defender_matches_reference_golden(name, golden_cases, precision, tol):
     g = golden_cases[name]
     x = _t(g['x'])
-    eng = _setup(g, rows=x.shape[0], rep=1)
+    eng = _setup(g, rows=x.shape[0], rep=1, precision=precision)
     eng.x_in.copy_(x.to(DEV))
     for i, e in enumerate(eng.eps):
         e.copy_(_t(g[f'eps_{i}']).to(DEV))
@@ -67,8 +71,8 @@ def test_defender_matches_reference_golden(name, golden_cases):
     torch.cuda.synchronize()
     e_g = _err(eng.dx, _t(g['grad_x']))
     gmax = float(np.abs(g['grad_x']).max())
-    print(f'{name}: purified {e_p:.2e} logits {e_l:.2e} grad {e_g:.2e} (|grad|max {gmax:.2e})')
-    assert e_p < TOL and e_l < TOL and e_g < TOL * max(1.0, gmax) and TOL <= TOL_SPEC
+    print(f'{name} [{precision}]: purified {e_p:.2e} logits {e_l:.2e} grad {e_g:.2e} (|grad|max {gmax:.2e})')
+    assert e_p < tol and e_l < tol and e_g < tol * max(1.0, gmax) and tol <= TOL_SPEC
 
 
 @pytest.mark.parametrize('name', CASES)
@@ -115,7 +119,8 @@ def test_multiple_backwards_per_forward_and_determinism(golden_cases):
     assert _err(g2, 2 * g1) < 1e-6
 
 
-def test_against_oracle_on_fresh_inputs():
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
+def test_against_oracle_on_fresh_inputs(precision, tol):
     """oracle (CPU) vs HIP on a mid-size config with 32-multiple channels (vectorised paths, every tile shape).
     The input-gradient is checked in two legs: through the NVAE alone (cotangent on the purified image: smooth, strict
     tolerance) and through the classifier, whose 2x2 max-pools make the gradient discontinuous at near-ties — a
@@ -144,7 +149,7 @@ def test_against_oracle_on_fresh_inputs():
     cot = torch.randn(logits.shape, generator=gen)
     (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
 
-    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV)
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV, precision=precision)
     eng.x_in.copy_(imgs.to(DEV))
     for b, e in zip(eng.eps, eps):
         b.copy_(e.to(DEV))
@@ -161,9 +166,9 @@ def test_against_oracle_on_fresh_inputs():
     torch.cuda.synchronize()
     diff = (eng.dx.cpu() - gx).double()
     rel_l2 = (diff.norm() / gx.double().norm()).item()
-    frac_off = (diff.abs() > TOL * max(1.0, gx.abs().max().item())).double().mean().item()
-    print(f'oracle parity: purified {e_p:.2e} logits {e_l:.2e} nvae-grad {e_gi:.2e} (max {gi_max:.2e}) '
+    frac_off = (diff.abs() > tol * max(1.0, gx.abs().max().item())).double().mean().item()
+    print(f'oracle parity [{precision}]: purified {e_p:.2e} logits {e_l:.2e} nvae-grad {e_gi:.2e} (max {gi_max:.2e}) '
           f'full-grad relL2 {rel_l2:.2e} frac_off {frac_off:.2e}')
-    assert e_p < TOL and e_l < TOL
-    assert e_gi < TOL * max(1.0, gi_max)
-    assert rel_l2 < 2e-2 and frac_off < 5e-3
+    assert e_p < tol and e_l < tol
+    assert e_gi < tol * max(1.0, gi_max)
+    assert rel_l2 < 2e-2 and frac_off < (5e-3 if precision == 'fp32' else 2e-2)

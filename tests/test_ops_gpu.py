@@ -164,6 +164,38 @@ def test_conv_split_k(N, H, Cin, Cout, K, splits, tile):
     assert L.lib.ga_conv2d(C.byref(d), None) == -1
 
 
+@pytest.mark.parametrize('N,H,Cin,Cout,K,act,tile', [(2, 8, 32, 40, 3, 1, 0), (2, 16, 64, 128, 3, 1, 1), (4, 8, 128, 64, 1, 0, 2),
+                                                     (2, 4, 256, 256, 3, 2, 3), (3, 8, 40, 24, 1, 3, 4), (1, 16, 8, 16, 3, 1, 0)])
+def test_conv_bf16x3(N, H, Cin, Cout, K, act, tile):
+    """split-bf16 contraction (w_hi/w_lo given): same op, ~2e-5 relative per product; asserted at 2e-4 of the output
+    scale, forward and transpose."""
+    pad = K // 2
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, K, K, seed=2, scale=1.0 / np.sqrt(Cin * K * K))
+    b = g(Cout, seed=3)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(ACTS[act](xr), w, b, padding=pad)
+    y = torch.empty(N, H, H, Cout, device=DEV)
+    wf = fwd_w(w)
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    hi2, lo2 = torch.empty_like(hi), torch.empty_like(lo)
+    L.check(L.lib.ga_split_bf16(wf.data_ptr(), hi2.data_ptr(), lo2.data_ptr(), wf.numel(), None), 'split')
+    torch.cuda.synchronize()
+    assert torch.equal(hi, hi2) and torch.equal(lo, lo2)
+    xd = nhwc(x)
+    run_conv(xd, wf, y, K, pad=pad, tile=tile, bias=b.to(DEV), pro_act=act, w_hi=hi, w_lo=lo)
+    close(nchw(y), ref, 2e-4, 'bf16x3 fwd')
+    cot = g(*ref.shape, seed=6)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    wb = bwd_w(w)
+    bh = wb.to(torch.bfloat16)
+    bl = (wb - bh.float()).to(torch.bfloat16)
+    dx = torch.empty(N, H, H, Cin, device=DEV)
+    run_conv(nhwc(cot), wb, dx, K, pad=K - 1 - pad, tile=tile, dact_x=xd, dact_act=act, lddact=Cin, w_hi=bh, w_lo=bl)
+    close(nchw(dx), gx, 2e-4, 'bf16x3 bwd')
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)
@@ -259,6 +291,19 @@ def test_se_chain(N, H, Cc):
     torch.cuda.synchronize()
     dt = nchw(cd) * ps.cpu().view(N, Cc, 1, 1) + pb.cpu().view(N, Cc, 1, 1)
     close(dt, gt, 1e-6, 'se backward')
+
+    # fused forms (reduction inside the excite kernel) must give the same numbers
+    hid2, g2, ps2, pb2 = (torch.empty_like(hid), torch.empty_like(gd), torch.empty_like(ps), torch.empty_like(pb))
+    f = L.SeExciteDesc()
+    f.t, f.w1, f.b1, f.w2, f.b2 = td.data_ptr(), *(v.data_ptr() for v in W)
+    f.hid, f.gate, f.N, f.C, f.Hd, f.P, f.res_scale = hid2.data_ptr(), g2.data_ptr(), N, Cc, Hd, H * H, 0.1
+    L.run(f)
+    close(g2, gate, 1e-6, 'fused gate')
+    f.backward, f.dout, f.pro_scale, f.pro_shift = 1, cd.data_ptr(), ps2.data_ptr(), pb2.data_ptr()
+    L.run(f)
+    torch.cuda.synchronize()
+    close(ps2, ps, 1e-6, 'fused ps')
+    close(pb2, pb, 1e-6 , 'fused pb')
 
 
 @pytest.mark.parametrize('N,h,Cc', [(2, 4, 16), (3, 8, 8), (1, 16, 4), (2, 1, 4)])
