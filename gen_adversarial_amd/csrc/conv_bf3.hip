@@ -29,7 +29,11 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 constexpr int BK3 = 32;     // k per LDS stage
 constexpr int LDB = 40;     // bf16 elements per LDS row (32 + 8 pad = 80 B)
 
-template <int WM, int WN, int TM, int TN, int PRO>
+// PRO: 0 none, 1 per-channel affine and/or activation, 2 per-(row,channel) affine (+ activation), 3 = SiLU only.
+// DUAL: a second K source (x2) exists.  Both are compile-time so that the steady-state loop body is one basic block:
+// the scheduler can then place the loader's VALU work (prologue + bf16 split of tile t+1) BETWEEN the MFMAs of tile t
+// (sched_group_barrier), instead of two waves per SIMD running their matrix phases and their VALU phases in lockstep.
+template <int WM, int WN, int TM, int TN, int PRO, bool DUAL>
 __global__ void __launch_bounds__(256)
 conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
                 const int vec_out) {
@@ -111,13 +115,13 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         const int c = c0 + 4 * c4;
         cur_c = c;
         okmask = 0;
-        const bool in_x = c0 < d.C1;
+        const bool in_x = DUAL ? c0 < d.C1 : true;
         const int lim = (in_x ? d.C1 : Ctot) - c0;
         const bool cval = 4 * c4 < lim;
         const int delta = (kh * d.Wi + kw) * (in_x ? d.ldx : d.ldx2) * 4;
         const int soffA = (in_x ? c0 : c0 - d.C1) * 4;
         const unsigned bit = 1u << tap;
-        if (in_x) {
+        if (!DUAL || in_x) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const bool valid = cval & ((maskA[i] & bit) != 0);
@@ -143,7 +147,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
             rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, off, soffB, 0);
         }
         if (PRO == 1) {
-            if (d.pro_scale) {
+            if (d.pro_scale) {          // uniform
                 const int pc = (in_x & cval) ? c : 0;
                 rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
                 rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
@@ -168,7 +172,12 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             floatx4 v = ra[i];
-            if (PRO != 0) {
+            if (PRO == 3) {                                  // SiLU, no affine: silu(0) = 0, padded taps stay zero
+                floatx4 pv = v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
+                v = (!DUAL || first) ? pv : v;
+            } else if (PRO != 0) {
                 floatx4 pv = v;
                 if (PRO == 2) pv = pv * rs[i] + rt[i];
                 else if (d.pro_scale) pv = pv * rs[0] + rt[0];
@@ -191,7 +200,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int row = rb0 + 64 * i;
-            if (row < BN) {
+            if (BN >= 64 || row < BN) {
                 *reinterpret_cast<uintx4*>(Bh + row * LDB + 8 * k8) = rbh[i];
                 *reinterpret_cast<uintx4*>(Bl + row * LDB + 8 * k8) = rbl[i];
             }
@@ -219,9 +228,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         finish_tile(0);
     }
     __syncthreads();
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) issue_tile();
+    auto mma_tile = [&](const int buf) {
         const __bf16* Ah = lds + buf * STAGE + (wm * TM * 32 + lrow) * LDB + 8 * lh;
         const __bf16* Al = Ah + BM * LDB;
         const __bf16* Bh = lds + buf * STAGE + 2 * BM * LDB + (wn * TN * 32 + lrow) * LDB + 8 * lh;
@@ -248,23 +255,52 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (t + 1 < t_end) finish_tile(buf ^ 1);
+    };
+
+    // steady state: a next tile exists -> no branch in the body; the staging math of tile t+1 is spread between the
+    // MFMAs of tile t (1 MFMA : 4 VALU : 1 DS, the matrix pipe takes 32 cycles per MFMA, a VALU op 4-8)
+    constexpr int NMFMA = TM * TN * 3 * (BK3 / 16);
+    auto body = [&](const int buf) {        // MFMAs of the staged tile || split + LDS write of the next one (already loaded)
+        mma_tile(buf);
+        finish_tile(buf ^ 1);
+#pragma unroll
+        for (int k = 0; k < NMFMA; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+        }
+    };
+    // the loads of tile t+1 are issued one whole iteration before their registers are consumed (right after the
+    // registers are freed by finish_tile), so the interleaved VALU never waits on memory
+    int buf = 0;
+    int t = t_begin;
+    if (t + 1 < t_end) issue_tile();                    // tile t_begin+1 in flight
+    for (; t + 2 < t_end; ++t) {
+        body(buf);
+        issue_tile();                                   // tile t+2
         __syncthreads();
+        buf ^= 1;
     }
+    if (t + 1 < t_end) {
+        body(buf);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (t_begin < t_end) mma_tile(buf);
 
     conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
 }
 
-template <int WM, int WN, int TM, int TN, int PRO>
+template <int WM, int WN, int TM, int TN, int PRO, bool DUAL>
 static void launch_bf3_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                             int Ktot, int nkc, int vec_out) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, PRO>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, PRO, DUAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, PRO>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, PRO, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -279,10 +315,15 @@ static int launch_bf3(const ga_conv_desc& d, hipStream_t stream, int vec_out, in
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
-    const int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
-    if (pro == 0) launch_bf3_inst<WM, WN, TM, TN, 0>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
-    else if (pro == 1) launch_bf3_inst<WM, WN, TM, TN, 1>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
-    else launch_bf3_inst<WM, WN, TM, TN, 2>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
+    if (pro == 1 && !d.pro_scale && d.pro_act == GA_ACT_SILU) pro = 3;
+#define GA_BF3(P, D) launch_bf3_inst<WM, WN, TM, TN, P, D>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out)
+    if (d.C2 > 0) {
+        if (pro == 0) GA_BF3(0, true); else if (pro == 1) GA_BF3(1, true); else if (pro == 2) GA_BF3(2, true); else GA_BF3(3, true);
+    } else {
+        if (pro == 0) GA_BF3(0, false); else if (pro == 1) GA_BF3(1, false); else if (pro == 2) GA_BF3(2, false); else GA_BF3(3, false);
+    }
+#undef GA_BF3
     return check_launch();
 }
 

@@ -376,12 +376,16 @@ class Engine:
     def apply_tuning(self, cache: dict):
         """set (tile, splits) of every conv from the cache; shapes not in the cache keep the library heuristic."""
         for d in self._conv_descs():
-            tile, splits = cache.get(conv_key(d), (0, 1))
+            ent = cache.get(conv_key(d), (0, 1, 1))
+            tile, splits = ent[0], ent[1]
+            use_bf3 = ent[2] if len(ent) > 2 else 1
             need = splits * d.N * d.Ho * d.Wo * d.Cout
             if splits > 1 and (self.ws is None or need > WS_FLOATS):
                 tile, splits = 0, 1
             d.tile, d.splits = int(tile), int(splits)
             d.ws, d.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
+            if not use_bf3:                      # this shape is faster on the exact fp32 kernel (small K or Cout)
+                d.w_hi, d.w_lo = None, None
         self.fwd.finalize()
         self.bwd.finalize()
 
@@ -398,7 +402,8 @@ class Engine:
             M = d.N * d.Ho * d.Wo
             T = d.KH * d.KW * ((d.C1 + d.C2 + 31) // 32)
             best = None
-            for tile in (1, 2, 3, 4):
+            modes = (1, 0) if d.w_hi else (0,)
+            for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4)]:
                 bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32)}[tile]
                 if bn >= 2 * max(32, d.Cout) and tile != 4:
                     continue
@@ -408,6 +413,8 @@ class Engine:
                         continue
                     t = L.ConvDesc.from_buffer_copy(d)
                     t.tile, t.splits = tile, splits
+                    if not use_bf3:
+                        t.w_hi, t.w_lo = None, None
                     t.ws, t.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
                     L.run(t, stream)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -418,10 +425,10 @@ class Engine:
                     e1.synchronize()
                     ms = e0.elapsed_time(e1) / reps
                     if best is None or ms < best[0]:
-                        best = (ms, tile, splits)
-            cache[key] = (best[1], best[2])
+                        best = (ms, tile, splits, use_bf3)
+            cache[key] = (best[1], best[2], best[3])
             if verbose:
-                print(f'tune {key}: tile {best[1]} splits {best[2]} {best[0] * 1e3:.1f} us', flush=True)
+                print(f'tune {key}: tile {best[1]} splits {best[2]} {best[0] * 1e3:.1f} us bf3 {best[3]}', flush=True)
         self.apply_tuning(cache)
         if save:
             with open(save, 'w') as f:
