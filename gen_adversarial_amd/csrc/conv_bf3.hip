@@ -287,6 +287,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         buf ^= 1;
     }
     if (t_begin < t_end) mma_tile(buf);
+    __syncthreads();        // every wave is done reading the operand tiles before the epilogue reuses the LDS
 
     conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
 }
@@ -351,6 +352,7 @@ __global__ void split_bf16_kernel(const float* w, __bf16* hi, __bf16* lo, const 
 }  // namespace ga
 
 extern "C" int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream) {
+    ga::clear_stale_error();
     if (!w || !hi || !lo || n <= 0) return GA_E_BADARG;
     long blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;

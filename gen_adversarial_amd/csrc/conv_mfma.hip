@@ -430,6 +430,7 @@ int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int v
 }  // namespace ga
 
 extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
+    ga::clear_stale_error();
     using namespace ga;
     if (!dp) return GA_E_BADARG;
     const ga_conv_desc& d = *dp;

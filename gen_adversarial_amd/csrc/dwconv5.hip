@@ -156,6 +156,7 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
 }  // namespace ga
 
 extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
+    ga::clear_stale_error();
     using namespace ga;
     if (!dp) return GA_E_BADARG;
     const ga_dwconv5_desc& d = *dp;

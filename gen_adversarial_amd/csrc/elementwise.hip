@@ -372,6 +372,7 @@ static inline unsigned grid_for(long items) {
 using namespace ga;
 
 extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->a || !d->out || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!aligned16(d->a) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
@@ -381,6 +382,7 @@ extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
 }
 
 extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->hid || !d->gate || d->N <= 0 || d->C <= 0 || d->Hd <= 0) return GA_E_BADARG;
     if (!d->backward && !d->m && !d->t) return GA_E_BADARG;
     if (d->backward && ((!d->dgate && !d->t) || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
@@ -397,6 +399,7 @@ extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
 }
 
 extern "C" int ga_se_apply(const ga_se_apply_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->skip || !d->t || !d->gate || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (d->skip_mode == 1 && ((d->H | d->W) & 1)) return GA_E_BADARG;
@@ -408,6 +411,7 @@ extern "C" int ga_se_apply(const ga_se_apply_desc* d, void* s) {
 }
 
 extern "C" int ga_bilinear_up2_bwd(const ga_bilinear_up2_bwd_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->dhigh || !d->dlow || d->N <= 0 || d->h <= 0 || d->w <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!aligned16(d->dhigh) || !aligned16(d->dlow)) return GA_E_ALIGN;
@@ -417,6 +421,7 @@ extern "C" int ga_bilinear_up2_bwd(const ga_bilinear_up2_bwd_desc* d, void* s) {
 }
 
 extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->mu_q || !d->eps || d->N <= 0 || d->h <= 0 || d->w <= 0 || d->NL <= 0) return GA_E_BADARG;
     if (d->ldq < d->NL || (d->p && d->ldp < 2 * d->NL)) return GA_E_BADARG;
     if (!d->backward && !d->z) return GA_E_BADARG;
@@ -427,6 +432,7 @@ extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
 }
 
 extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->logits || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->nmix <= 0) return GA_E_BADARG;
     if (d->nmix > DML_MAXMIX) return GA_E_UNSUPPORTED;
     if (d->ld < d->nmix * 10) return GA_E_BADARG;
@@ -438,6 +444,7 @@ extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
 }
 
 extern "C" int ga_maxpool2(const ga_maxpool2_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->x || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
     if ((d->H | d->W) & 1) return GA_E_UNSUPPORTED;
     if (d->C % 4) return GA_E_UNSUPPORTED;
@@ -449,6 +456,7 @@ extern "C" int ga_maxpool2(const ga_maxpool2_desc* d, void* s) {
 }
 
 extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
+    ga::clear_stale_error();
     if (!d || !d->x_nchw || d->N <= 0 || d->C <= 0 || d->H <= 0 || d->W <= 0 || d->rep <= 0 || d->N % d->rep) return GA_E_BADARG;
     if ((d->noise_nchw == nullptr) != (d->noise_coef == nullptr)) return GA_E_BADARG;
     if (!d->backward && !d->y_nhwc) return GA_E_BADARG;
@@ -459,6 +467,7 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
 }
 
 extern "C" int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* s) {
+    ga::clear_stale_error();
     if (!x || !y || n <= 0) return GA_E_BADARG;
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)s, x, y, n, alpha, beta);
     return check_launch();

@@ -54,6 +54,9 @@ __device__ __forceinline__ float act_bwd_fast(float u, int act) {
     }
 }
 
+// a sticky error left by an unrelated earlier HIP call must not be blamed on our launch: entry points clear it first
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { g_last_err = e; return GA_E_LAUNCH; }
