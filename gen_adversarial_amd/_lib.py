@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; libga_ops.so needs the same SONAME.  Importing torch FIRST makes the
+# dynamic loader bind our library to the HIP runtime torch already initialised (one runtime per process: streams and
+# device pointers are shared).  Loading ours first would pull the system ROCm copy and leave two runtimes in the process
+# ("no ROCm-capable device is detected" on the second one).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libga_ops.so')
 

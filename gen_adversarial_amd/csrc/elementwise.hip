@@ -38,11 +38,11 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
 // SE excite: relu(linear_1) -> sigmoid(linear_2) (architecture.py:57-58) and its backward.  One block per row.
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc d) {
-    extern __shared__ float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_in = sm;            // C
     float* s_hid = sm + d.C;     // Hd
-    float* s_part = sm + d.C + d.Hd;   // fused reduction: [PL][C]
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* s_part = sm + ((d.C + d.Hd + 3) & ~3);   // fused reduction [PL][C] / FC partials, 16-B aligned
+    const int n = blockIdx.x, tid = threadIdx.x;
     if (d.t) {
         // fused squeeze / d(gate): channel-quad lanes x pixel lanes, fixed summation order
         const int C4 = d.C >> 2, PL = 256 / C4;
@@ -67,22 +67,57 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
         }
         __syncthreads();
     }
+    // thread -> (hidden unit j, channel chunk): all 256 threads stream w1 / w2 with 16-B loads, chunk partials are
+    // combined through LDS in a fixed order (bitwise reproducible)
+    const int C4 = d.C >> 2;
+    int chunks = 256 / d.Hd;
+    if (chunks > C4) chunks = C4;
+    const int per = (C4 + chunks - 1) / chunks;                 // channel-quads per chunk
+    float* s_red = s_part;                                       // [Hd][chunks] partials (reuses the reduction scratch)
     if (!d.backward) {
         if (!d.t) {
             for (int c = tid; c < d.C; c += 256) s_in[c] = d.m[(size_t)n * d.C + c];
             __syncthreads();
         }
-        for (int j = wave; j < d.Hd; j += 4) {
-            float acc = 0.f;
-            for (int c = lane; c < d.C; c += 64) acc += d.w1[(size_t)j * d.C + c] * s_in[c];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lane == 0) { const float h = acc + d.b1[j]; s_hid[j] = h; d.hid[(size_t)n * d.Hd + j] = h; }
+        {
+            const int j = tid / chunks, ch = tid % chunks;
+            if (j < d.Hd) {
+                float acc = 0.f;
+                const int q0 = ch * per, q1 = min(C4, q0 + per);
+                if ((d.C & 3) == 0) {
+                    for (int q = q0; q < q1; ++q) {
+                        const floatx4 w = *reinterpret_cast<const floatx4*>(d.w1 + (size_t)j * d.C + 4 * q);
+                        const floatx4 v = *reinterpret_cast<const floatx4*>(s_in + 4 * q);
+                        acc += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+                    }
+                }
+                s_red[j * chunks + ch] = acc;
+            }
+        }
+        __syncthreads();
+        if (tid < d.Hd) {
+            float h = d.b1[tid];
+            for (int k = 0; k < chunks; ++k) h += s_red[tid * chunks + k];
+            if (d.C & 3) {                                       // odd channel counts: plain loop
+                h = d.b1[tid];
+                for (int c = 0; c < d.C; ++c) h += d.w1[(size_t)tid * d.C + c] * s_in[c];
+            }
+            s_hid[tid] = h;
+            d.hid[(size_t)n * d.Hd + tid] = h;
         }
         __syncthreads();
         for (int c = tid; c < d.C; c += 256) {
             float acc = d.b2[c];
-            for (int j = 0; j < d.Hd; ++j) acc += d.w2[(size_t)c * d.Hd + j] * fmaxf(s_hid[j], 0.f);
+            const float* w = d.w2 + (size_t)c * d.Hd;
+            if ((d.Hd & 3) == 0) {
+                for (int j = 0; j < d.Hd; j += 4) {
+                    const floatx4 wv = *reinterpret_cast<const floatx4*>(w + j);
+                    acc += wv[0] * fmaxf(s_hid[j], 0.f) + wv[1] * fmaxf(s_hid[j + 1], 0.f) +
+                           wv[2] * fmaxf(s_hid[j + 2], 0.f) + wv[3] * fmaxf(s_hid[j + 3], 0.f);
+                }
+            } else {
+                for (int j = 0; j < d.Hd; ++j) acc += w[j] * fmaxf(s_hid[j], 0.f);
+            }
             d.gate[(size_t)n * d.C + c] = sigmoidf_(acc);
         }
     } else {
@@ -93,12 +128,25 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             s_in[c] = dg * g * (1.f - g);
         }
         __syncthreads();
-        for (int j = wave; j < d.Hd; j += 4) {
+        // dh[j] = sum_c w2[c][j] * ds[c]: the [C][Hd] matrix is streamed once with coalesced loads (thread t takes
+        // elements t, t+256, ... : its j = t % Hd is fixed because Hd divides 256), partials combined in a fixed order
+        if (256 % d.Hd == 0) {
+            const int j = tid % d.Hd, nch = 256 / d.Hd, ch = tid / d.Hd;
             float acc = 0.f;
-            for (int c = lane; c < d.C; c += 64) acc += d.w2[(size_t)c * d.Hd + j] * s_in[c];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lane == 0) s_hid[j] = d.hid[(size_t)n * d.Hd + j] > 0.f ? acc : 0.f;
+            for (int c = ch; c < d.C; c += nch) acc += d.w2[(size_t)c * d.Hd + j] * s_in[c];
+            s_red[j * nch + ch] = acc;
+            __syncthreads();
+            if (tid < d.Hd) {
+                float a2 = 0.f;
+                for (int k = 0; k < nch; ++k) a2 += s_red[tid * nch + k];
+                s_hid[tid] = d.hid[(size_t)n * d.Hd + tid] > 0.f ? a2 : 0.f;
+            }
+        } else {
+            if (tid < d.Hd) {
+                float a2 = 0.f;
+                for (int c = 0; c < d.C; ++c) a2 += d.w2[(size_t)c * d.Hd + tid] * s_in[c];
+                s_hid[tid] = d.hid[(size_t)n * d.Hd + tid] > 0.f ? a2 : 0.f;
+            }
         }
         __syncthreads();
         const float invP = 1.0f / (float)d.P;
@@ -221,11 +269,27 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
 // DiscMixLogistic.mean + denormalise (distributions.py:103-129,231-254; models.py:271-274); one thread per pixel
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DML_MAXMIX = 16;
+constexpr int DML_ROWS = 128;      // pixels per workgroup pass (LDS: 128 x (ld+1) floats)
 
-__global__ void __launch_bounds__(256) dml_kernel(const ga_dml_desc d, const long npix) {
+__global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, const long npix) {
+    // each thread owns one pixel, but a pixel's `ld` logits are 400 B apart from its neighbour's: the block first copies
+    // its 128 rows into LDS with coalesced 4-B accesses (row pitch ld+1: conflict-free per-thread reads), computes from
+    // LDS, and in the backward pass writes dlogits back through the same staging buffer.
+    extern __shared__ float dml_s[];
     const int HW = d.H * d.W;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
-        const float* l = d.logits + i * d.ld;
+    const int pitch = d.ld + 1;
+    for (long base = (long)blockIdx.x * DML_ROWS; base < npix; base += (long)gridDim.x * DML_ROWS) {
+        const int nrow = (int)min((long)DML_ROWS, npix - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
+            const int r = k / d.ld, c = k - r * d.ld;
+            dml_s[r * pitch + c] = d.logits[base * d.ld + k];
+        }
+        __syncthreads();
+        const long i = base + threadIdx.x;
+        const bool active = threadIdx.x < nrow;
+        float* l = dml_s + threadIdx.x * pitch;
+        if (active) {
         const int nm = d.nmix;
         float p[DML_MAXMIX];
         float mx = -INFINITY;
@@ -265,7 +329,7 @@ __global__ void __launch_bounds__(256) dml_kernel(const ga_dml_desc d, const lon
             const float dmu1 = dgp, dK0 = dgp * r;
             dr += dgp * K0;
             const float dmu0 = (mu0 >= -1.f && mu0 <= 1.f) ? dr : 0.f;
-            float* o = d.dlogits + i * d.ld;
+            float* o = l;                                   // staged: written back coalesced below
             float dpk[DML_MAXMIX];
             float dot = 0.f;
             for (int k = 0; k < nm; ++k) {
@@ -280,6 +344,14 @@ __global__ void __launch_bounds__(256) dml_kernel(const ga_dml_desc d, const lon
             }
             for (int k = 0; k < nm; ++k) o[k] = p[k] * (dpk[k] - dot);
             for (int k = nm + 9 * nm; k < d.ld; ++k) o[k] = 0.f;
+        }
+        }   // active
+        if (d.backward) {
+            __syncthreads();
+            for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
+                const int r = k / d.ld, c = k - r * d.ld;
+                d.dlogits[base * d.ld + k] = dml_s[r * pitch + c];
+            }
         }
     }
 }
@@ -386,12 +458,14 @@ extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
     if (!d || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->hid || !d->gate || d->N <= 0 || d->C <= 0 || d->Hd <= 0) return GA_E_BADARG;
     if (!d->backward && !d->m && !d->t) return GA_E_BADARG;
     if (d->backward && ((!d->dgate && !d->t) || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
-    size_t lds = (size_t)(d->C + d->Hd) * sizeof(float);
+    size_t lds = (size_t)(d->C + d->Hd + 4 + 256) * sizeof(float);     // + [Hd][chunks] partials of the FC phases
+    if (d->Hd > 256) return GA_E_UNSUPPORTED;
     if (d->t) {
         if (d->P <= 0 || (d->backward && !d->dout)) return GA_E_BADARG;
         if (d->C % 4 || d->C > 1024) return GA_E_UNSUPPORTED;
         if (!aligned16(d->t) || (d->dout && !aligned16(d->dout))) return GA_E_ALIGN;
-        lds += (size_t)(256 / (d->C / 4)) * d->C * sizeof(float);
+        const size_t red = (size_t)(256 / (d->C / 4)) * d->C * sizeof(float);
+        if (red > 256 * sizeof(float)) lds += red - 256 * sizeof(float);
     }
     if (lds > 64 * 1024) return GA_E_UNSUPPORTED;
     hipLaunchKernelGGL(se_excite_kernel, dim3(d->N), dim3(256), lds, (hipStream_t)s, *d);
@@ -439,7 +513,11 @@ extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
     if (!d->backward && !d->img_nchw && !d->img_nhwc) return GA_E_BADARG;
     if (d->backward && (!d->dlogits || (!d->dimg_nhwc && !d->dimg_nchw))) return GA_E_BADARG;
     const long npix = (long)d->N * d->H * d->W;
-    hipLaunchKernelGGL(dml_kernel, dim3(grid_for(npix)), dim3(256), 0, (hipStream_t)s, *d, npix);
+    const size_t lds = (size_t)DML_ROWS * (d->ld + 1) * sizeof(float);
+    if (lds > 64 * 1024) return GA_E_UNSUPPORTED;
+    long blocks = (npix + DML_ROWS - 1) / DML_ROWS;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dml_kernel, dim3((unsigned)blocks), dim3(DML_ROWS), lds, (hipStream_t)s, *d, npix);
     return check_launch();
 }
 
