@@ -119,6 +119,8 @@ def main():
     ap.add_argument('--rows', type=int, default=256)
     ap.add_argument('--eot', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
+                    help='collective backend; gloo (CPU tensors) only to rehearse N>1 on a box with fewer GPUs than ranks')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default='bf16x3',
                     help="dense contractions: 'bf16x3' = 3 bf16 MFMAs per product (logits within ~2e-5 of fp32), 'fp32' = exact f32 MFMA")
     args = ap.parse_args()
@@ -128,13 +130,21 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    device = f'cuda:{local_rank}'
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % ndev      # rehearsal: several ranks share one GPU
+    if local_rank >= ndev and args.backend == 'nccl':
+        raise SystemExit(f'rank {rank}: no GPU {local_rank} on this node (use --backend gloo only to rehearse)')
+    torch.cuda.set_device(dev_index)
+    device = f'cuda:{dev_index}'
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+    coll_dev = device if args.backend == 'nccl' else 'cpu'
 
     log(f'rank {rank}/{world}: building weights + engine ({args.rows} rows)')
     eng, model = build_model(device, args.rows, args.eot, seed=0, precision=args.precision)
@@ -167,12 +177,13 @@ def main():
     correct = (logits.argmax(dim=1) == labels).sum().view(1).float()
     counters = torch.stack([correct.squeeze(0), torch.tensor(float(labels.numel()), device=device)])
     if dist is not None:
+        counters = counters.to(coll_dev)
         gathered = [torch.zeros_like(counters) for _ in range(world)]
         dist.all_gather(gathered, counters)
         counters = torch.stack(gathered).sum(dim=0)
     sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=device)
+    t = torch.tensor([dt], device=coll_dev if dist is not None else device)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
