@@ -4,13 +4,15 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `interpolation_alphas`, `alpha_attenuation`, `initial_noise_eps`, `gaussian_blur_input`), sets `args.image_size`,
 `args.attacks` and attaches `defense_model.get_purified`.
 
-Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only) and 'ours' (NVAE purifier).
+Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only) and 'ours' (NVAE purifier), with the
+reference's attack set (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
 Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
 """
 from argparse import Namespace
 
 import yaml
 
+from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
 from ..defenses.ours.models import CelebaIdentityClassifier, NVAEDefenseModel
 from ..defenses.wrappers import EoTWrapper
@@ -22,9 +24,15 @@ def load(args: Namespace):
 
     if args.experiment == 'ids':
         args.image_size = 64
-        # The reference's evaluation attacks (DeepFool / C&W / AutoAttack, load_defense.py:48-52) are the "next" row f1;
-        # PGD-Linf eps=8/255 is the attack BASELINE.json names and follows the same call protocol.
-        args.attacks = {'pgd': PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)}
+        # the reference's evaluation attacks with its hyper-parameters for this experiment (load_defense.py:48-52)
+        args.attacks = {
+            'deepfool': DeepFool(num_classes=8, overshoot=0.02, max_iter=128),
+            'c&w': CW(c=16., kappa=0.05, steps=1024, lr=5e-3, n_restarts=8),
+            'autoattack': AutoAttack()
+        }
+        # PGD-Linf eps=8/255 is the attack BASELINE.json names (not in the reference tree); same call protocol,
+        # selected with `--attack pgd`
+        args.pgd = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)
         base_classifier = CelebaIdentityClassifier(d_params.classifier_path, args.device)
         hl_instance = NVAEDefenseModel
     elif args.experiment in ('gender', 'cars'):

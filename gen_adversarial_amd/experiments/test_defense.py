@@ -143,7 +143,8 @@ def parse_args(argv=None):
     p.add_argument('--defense_type', type=str, choices=['base', 'A-VAE', 'ND-VAE', 'trades', 'ours', 'ablation'])
     p.add_argument('--experiment', type=str, choices=['gender', 'ids', 'cars'])
     p.add_argument('--config', type=str, required=True)
-    p.add_argument('--attack', type=str, default=None)
+    p.add_argument('--attack', type=str, choices=['deepfool', 'c&w', 'autoattack', 'pgd'], default=None,
+                   help='If passed, try a specific attack only. Otherwise, try all (the reference\'s three).')
     args = p.parse_args(argv)
     args.results_folder = f'./results/{args.config.split("/")[-1][:-5]}/'
     os.makedirs(args.results_folder, exist_ok=True)
@@ -161,7 +162,9 @@ def main():
 
     def make_model(a):
         a, m = load(a)
-        if a.attack is not None:
+        if a.attack == 'pgd':
+            a.attacks = {'pgd': a.pgd}
+        elif a.attack is not None:
             a.attacks = {k: v for k, v in a.attacks.items() if k == a.attack}
         return a, m
     size = {'ids': 64, 'gender': 256, 'cars': 128}[args.experiment]

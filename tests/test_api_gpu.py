@@ -55,7 +55,7 @@ def _oracle(setup, x, eps, noise, rep):
 
 def test_eot_logits_grad_and_retain_graph(setup):
     args, model, *_ = setup
-    assert args.image_size == 64 and 'pgd' in args.attacks
+    assert args.image_size == 64 and set(args.attacks) == {'deepfool', 'c&w', 'autoattack'}
     spec = build_spec(CFG, RES)
     g = torch.Generator().manual_seed(0)
     x = torch.rand(1, *RES, generator=g)
@@ -127,11 +127,29 @@ def test_pgd_attack_protocol(setup):
     x = torch.rand(1, *RES, device=DEV)
     with torch.no_grad():
         label = model(x).argmax(dim=1)
-    atk = args.attacks['pgd']
+    atk = args.pgd
     atk.steps = 3
     success, bound, adv = atk(x, label, model)
     assert isinstance(success, bool) and isinstance(bound, float) and adv.shape == x.shape
     assert bound <= 8.0 / 255.0 + 1e-6 and 0.0 <= adv.min().item() and adv.max().item() <= 1.0
+
+
+def test_reference_attacks_drive_the_hip_defender(setup):
+    """DeepFool (per-class backward on one forward), APGD and FGSM against the stochastic HIP defender: protocol and
+    invariants (the numbers themselves are pinned on the CPU against the reference, tests/test_attacks_cpu.py)."""
+    from gen_adversarial_amd.attacks.l2_attacks import APGDAttack, DeepFool, FGSM
+    args, model, *_ = setup
+    x = torch.rand(1, *RES, device=DEV)
+    with torch.no_grad():
+        label = model(x).argmax(dim=1)
+    s, b, adv = DeepFool(num_classes=4, overshoot=0.02, max_iter=3)(x, label, model)
+    assert isinstance(s, bool) and adv.shape == x.shape and torch.isfinite(adv).all()
+    s, b, adv = APGDAttack(n_iter=3, rho=0.75, max_bound=0.5, ce_loss=True)(x, label, model)
+    assert b <= 0.5 + 1e-4 and 0.0 <= adv.min().item() and adv.max().item() <= 1.0
+    s, b, adv = APGDAttack(n_iter=2, rho=0.75, max_bound=0.5, ce_loss=False)(x, label, model)
+    assert b <= 0.5 + 1e-4
+    s, b, adv = FGSM(l2_bound=2.0)(x, label, model)
+    assert abs((adv - x).flatten().norm().item()) <= 2.0 + 1e-3
 
 
 def test_base_classifier_path(setup, tmp_path):
