@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'libga_ops.so')
 
 GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU = 0, 1, 2, 3
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
- GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY) = range(1, 12)
+ GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR) = range(1, 13)
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -95,10 +95,14 @@ class AxpbyDesc(C.Structure):
     _fields_ = [('x', fp), ('y', fp), ('n', C.c_long), ('alpha', f32), ('beta', f32)]
 
 
+class BlurDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('taps', fp), ('planes', i32), ('H', i32), ('W', i32), ('k', i32), ('backward', i32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [('conv', ConvDesc), ('dw', DwDesc), ('red', ReduceDesc), ('se', SeExciteDesc), ('app', SeApplyDesc),
                 ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
-                ('io', ImageIoDesc), ('ax', AxpbyDesc)]
+                ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc)]
 
 
 class Op(C.Structure):
@@ -107,14 +111,15 @@ class Op(C.Structure):
 
 _KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_OP_SE_EXCITE: 'se',
                GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
-               GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax'}
+               GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur'}
 _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
               SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
-              DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY}
+              DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY,
+              BlurDesc: GA_OP_BLUR}
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -126,7 +131,7 @@ def _load():
     for n, d in (('ga_conv2d', ConvDesc), ('ga_dwconv5', DwDesc), ('ga_rowchan_reduce', ReduceDesc),
                  ('ga_se_excite', SeExciteDesc), ('ga_se_apply', SeApplyDesc), ('ga_bilinear_up2_bwd', BilinearBwdDesc),
                  ('ga_sampler_mix', SamplerDesc), ('ga_dml_mean', DmlDesc), ('ga_maxpool2', MaxpoolDesc),
-                 ('ga_image_io', ImageIoDesc)):
+                 ('ga_image_io', ImageIoDesc), ('ga_gauss_blur', BlurDesc)):
         f = getattr(lib, n)
         f.argtypes = [C.POINTER(d), C.c_void_p]
         f.restype = C.c_int
@@ -171,7 +176,7 @@ def make_op(desc) -> Op:
 
 _DIRECT = {ConvDesc: 'ga_conv2d', DwDesc: 'ga_dwconv5', ReduceDesc: 'ga_rowchan_reduce', SeExciteDesc: 'ga_se_excite',
            SeApplyDesc: 'ga_se_apply', BilinearBwdDesc: 'ga_bilinear_up2_bwd', SamplerDesc: 'ga_sampler_mix',
-           DmlDesc: 'ga_dml_mean', MaxpoolDesc: 'ga_maxpool2', ImageIoDesc: 'ga_image_io'}
+           DmlDesc: 'ga_dml_mean', MaxpoolDesc: 'ga_maxpool2', ImageIoDesc: 'ga_image_io', BlurDesc: 'ga_gauss_blur'}
 
 
 def run(desc, stream: int = 0):

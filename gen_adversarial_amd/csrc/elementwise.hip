@@ -427,6 +427,58 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// separable Gaussian blur, reflect border (kornia gaussian_blur2d semantics), one image plane per workgroup in LDS
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int t, const int n) {       // 'reflect' (no edge repeat): -1 -> 1, n -> n-2
+    if (t < 0) t = -t;
+    if (t >= n) t = 2 * (n - 1) - t;
+    return t;
+}
+
+// forward line filter: out[i] = sum_k g[k] in[reflect(i + k - p)];  adjoint: out[j] = sum over (i,k) with reflect(i+k-p) = j
+__device__ __forceinline__ float blur_tap_sum(const float* line, const int stride, const int n, const int i, const float* g,
+                                              const int k, const bool adjoint) {
+    const int p = k / 2;
+    float acc = 0.f;
+    if (!adjoint) {
+        for (int q = 0; q < k; ++q) acc += g[q] * line[reflect_idx(i + q - p, n) * stride];
+    } else {
+        // sources t that reflect onto j = i: t = j, t = -j (j >= 1), t = 2(n-1) - j (j <= n-2); t = i' + q - p
+        for (int q = 0; q < k; ++q) {
+            const int a = i - q + p;
+            if (a >= 0 && a < n) acc += g[q] * line[a * stride];
+            if (i >= 1) { const int b2 = -i - q + p; if (b2 >= 0 && b2 < n) acc += g[q] * line[b2 * stride]; }
+            if (i <= n - 2) { const int c2 = 2 * (n - 1) - i - q + p; if (c2 >= 0 && c2 < n) acc += g[q] * line[c2 * stride]; }
+        }
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) gauss_blur_kernel(const ga_blur_desc d) {
+    extern __shared__ float bl_s[];
+    float* a = bl_s;                       // [H][W]
+    float* b = bl_s + d.H * d.W;           // [H][W]
+    float* g = b + d.H * d.W;              // [k]
+    const int HW = d.H * d.W;
+    const float* src = d.x + (size_t)blockIdx.x * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) a[i] = src[i];
+    for (int i = threadIdx.x; i < d.k; i += 256) g[i] = d.taps[i];
+    __syncthreads();
+    // kornia filters along x (kernel 1 x k) then along y; the adjoint applies the transposed passes in reverse order
+    const bool adj = d.backward != 0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / d.W, w = i - h * d.W;
+        b[i] = adj ? blur_tap_sum(a + w, d.W, d.H, h, g, d.k, true) : blur_tap_sum(a + h * d.W, 1, d.W, w, g, d.k, false);
+    }
+    __syncthreads();
+    float* dst = d.y + (size_t)blockIdx.x * HW;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int h = i / d.W, w = i - h * d.W;
+        dst[i] = adj ? blur_tap_sum(b + h * d.W, 1, d.W, w, g, d.k, true) : blur_tap_sum(b + w, d.W, d.H, h, g, d.k, false);
+    }
+}
+
 __global__ void __launch_bounds__(256) axpby_kernel(const float* x, float* y, const long n, const float a, const float b) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
@@ -541,6 +593,16 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
     if (d->backward && (!d->dy_nhwc || !d->dx_nchw)) return GA_E_BADARG;
     const long total = (long)d->N * d->C * d->H * d->W;
     hipLaunchKernelGGL(image_io_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
+    return check_launch();
+}
+
+extern "C" int ga_gauss_blur(const ga_blur_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || !d->y || !d->taps || d->planes <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0) return GA_E_BADARG;
+    if (!(d->k & 1) || d->k / 2 >= d->H || d->k / 2 >= d->W) return GA_E_UNSUPPORTED;
+    const size_t lds = ((size_t)2 * d->H * d->W + d->k) * sizeof(float);
+    if (lds > 64 * 1024) return GA_E_UNSUPPORTED;            // planes up to ~90 x 90; larger images are a next row
+    hipLaunchKernelGGL(gauss_blur_kernel, dim3(d->planes), dim3(256), lds, (hipStream_t)s, *d);
     return check_launch();
 }
 

@@ -180,9 +180,6 @@ class MLVGMDefenseModel(ABC, _EngineOwner):
         super().__init__()
         self.eps = initial_noise_eps
         self.blur_input = apply_gaussian_blur
-        if self.blur_input:
-            raise NotImplementedError('gaussian_blur_input (kornia gaussian_blur2d, abstract_models.py:145-159) is a '
-                                      '"next" row: not built yet')
         self._init_engines(device)
         self.classifier = classifier
         self.classifier.set_device(device)

@@ -99,7 +99,7 @@ class Engine:
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
-                 store: Optional[WeightStore] = None, precision: str = 'bf16x3'):
+                 store: Optional[WeightStore] = None, precision: str = 'bf16x3', blur: bool = False):
         if rows % rep:
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.device = torch.device(device)
@@ -121,6 +121,7 @@ class Engine:
             raise ValueError(f'{len(self.spec.groups)} interpolation alphas expected, got {len(self.alphas)}')
         self.temperature = float(temperature)
         self.noise_eps = float(noise_eps)
+        self.blur = bool(blur)
         self.need_backward = need_backward
         self.bytes = 0
         self.acts = {}                       # name -> Act (debugging / tests)
@@ -337,16 +338,37 @@ class Engine:
         self.dx = self.alloc((R // self.rep, 3, H, H))
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
 
+        # optional Gaussian blur of the input (abstract_models.py:145-159): deterministic, so it is applied to the B
+        # images before the EoT repeat; k = 2^(sqrt(H)//2) - 1 taps, sigma 1, reflect border (kornia semantics)
+        x_src, dx_dst = self.x_in, self.dx
+        if self.blur:
+            import math
+            k = int(2 ** (math.sqrt(H) // 2) - 1)
+            xs = torch.arange(k, dtype=torch.float64) - (k - 1) / 2.0
+            g = torch.exp(-xs.pow(2) / 2.0)
+            taps = self.devd(f'blur_taps_{k}', lambda: {'g': (g / g.sum()).float()})['g']
+            x_src = self.alloc((R // self.rep, 3, H, H))
+            dx_dst = self.alloc((R // self.rep, 3, H, H))
+            bl = L.BlurDesc()
+            bl.x, bl.y, bl.taps, bl.planes, bl.H, bl.W, bl.k, bl.backward = _ptr(self.x_in), _ptr(x_src), _ptr(taps), (R // self.rep) * 3, H, H, k, 0
+            self.fwd.add(bl, 'gauss_blur')
+
+            def bwd_blur():
+                b = L.BlurDesc()
+                b.x, b.y, b.taps, b.planes, b.H, b.W, b.k, b.backward = _ptr(dx_dst), _ptr(self.dx), _ptr(taps), (R // self.rep) * 3, H, H, k, 1
+                self.bwd.add(b, 'gauss_blur^T')
+            self._bwd_steps.append(bwd_blur)
+
         x0 = Act(self, R, H, H, 3, 'x0')
         io = L.ImageIoDesc()
-        io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(self.x_in), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
+        io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
         io.N, io.C, io.H, io.W, io.rep, io.backward = R, 3, H, H, self.rep, 0
         self.fwd.add(io, 'image_in')
 
         def bwd_image():
             b = L.ImageIoDesc()
-            b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(self.x_in), _ptr(self.noise), _ptr(self.noise_coef)
-            b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(self.dx)
+            b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef)
+            b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(dx_dst)
             b.N, b.C, b.H, b.W, b.rep, b.backward = R, 3, H, H, self.rep, 1
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)

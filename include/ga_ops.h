@@ -199,6 +199,16 @@ typedef struct ga_image_io_desc {
 } ga_image_io_desc;
 int ga_image_io(const ga_image_io_desc* d, void* stream);
 
+/* Separable Gaussian blur of image planes with 'reflect' border (kornia.filters.gaussian_blur2d as called by
+ * MLVGMDefenseModel.apply_gaussian_blur, src/defenses/ours/abstract_models.py:145-159: k = 2^(sqrt(H)//2) - 1 taps,
+ * sigma 1).  x, y: [planes][H][W] (NCHW images seen as N*C planes); taps: [k] normalised weights, k odd, k/2 < H, W.
+ * backward = the exact adjoint (reflect padding included): given dy in `x`, writes dx to `y`. */
+typedef struct ga_blur_desc {
+    const float* x; float* y; const float* taps;
+    int planes, H, W, k; int backward;
+} ga_blur_desc;
+int ga_gauss_blur(const ga_blur_desc* d, void* stream);
+
 /* w[n] fp32 -> hi[n], lo[n] bf16 with hi = bf16(w), lo = bf16(w - hi) (weight preparation for w_hi / w_lo) */
 int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream);
 
@@ -210,7 +220,7 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
  * ------------------------------------------------------------------------------------------------------------------ */
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
-                  GA_OP_AXPBY = 11 };
+                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_op {
     int kind;
@@ -218,7 +228,7 @@ typedef struct ga_op {
     union {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
-        ga_axpby_desc ax;
+        ga_axpby_desc ax; ga_blur_desc blur;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -172,3 +172,37 @@ def test_against_oracle_on_fresh_inputs(precision, tol):
     assert e_p < tol and e_l < tol
     assert e_gi < tol * max(1.0, gi_max)
     assert rel_l2 < 2e-2 and frac_off < (5e-3 if precision == 'fp32' else 2e-2)
+
+
+def test_blur_and_noise_preprocessing_against_oracle():
+    """gaussian_blur_input + initial_noise_eps (configs/ours_cosine_blur_ids.yaml style) through the whole path."""
+    from oracle import defender_oracle as D
+    cfg = {'initial_channels': 8, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 2, 'num_scales': 3,
+           'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
+           'num_latent_per_group': 4, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+    res = (3, 64, 64)
+    spec = build_spec(cfg, res)
+    sd = init_nvae_state_dict(cfg, res, 8)
+    vspec = build_vgg_spec(10, 16)
+    vsd = init_vgg_state_dict(10, 16, 9)
+    rows, rep = 6, 3
+    alphas = [0.5] * len(spec.groups)
+    gen = torch.Generator().manual_seed(3)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, 4, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    noise = torch.randn(rows, 3, 64, 64, generator=gen)
+    xr = imgs.clone().requires_grad_(True)
+    logits, purified = D.nvae_defender(sd, spec, vsd, vspec, xr.repeat_interleave(rep, dim=0), alphas, eps, noise, 2.0, blur=True)
+    cot = torch.randn(purified.shape, generator=gen)
+    (gx,) = torch.autograd.grad((purified * cot).sum(), [xr])
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, noise_eps=2.0, blur=True, device=DEV, precision='fp32')
+    eng.x_in.copy_(imgs.to(DEV))
+    for b, e in zip(eng.eps, eps):
+        b.copy_(e.to(DEV))
+    _load_noise(eng, noise, 2.0)
+    eng.forward()
+    eng.dpurified.copy_(cot.to(DEV))
+    eng.backward(from_logits=False, from_purified=True)
+    torch.cuda.synchronize()
+    assert _err(eng.purified, purified) < TOL and _err(eng.logits, logits) < TOL
+    assert _err(eng.dx, gx) < TOL * max(1.0, gx.abs().max().item())

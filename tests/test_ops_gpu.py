@@ -433,6 +433,33 @@ def test_image_io():
     close(dx, gx, 1e-6, 'image bwd')
 
 
+@pytest.mark.parametrize('H,k', [(64, 15), (32, 7), (16, 3), (20, 9)])
+def test_gauss_blur_forward_and_adjoint(H, k):
+    from oracle import defender_oracle as D
+    x = torch.rand(2, 3, H, H, generator=torch.Generator().manual_seed(1))
+    taps = D.gaussian_kernel1d(k)
+    xr = x.clone().requires_grad_(True)
+    p = k // 2
+    y = F.pad(xr, (p, p, p, p), mode='reflect')
+    y = F.conv2d(y, taps.view(1, 1, 1, k).expand(3, 1, 1, k), groups=3)
+    ref = F.conv2d(y, taps.view(1, 1, k, 1).expand(3, 1, k, 1), groups=3)
+    if H == 64:
+        np.testing.assert_allclose(D.apply_gaussian_blur(x).numpy(), ref.detach().numpy(), atol=1e-6)   # k = 15 at 64x64
+    xd, td = x.to(DEV), taps.to(DEV)
+    out = torch.empty_like(xd)
+    d = L.BlurDesc()
+    d.x, d.y, d.taps, d.planes, d.H, d.W, d.k = xd.data_ptr(), out.data_ptr(), td.data_ptr(), 6, H, H, k
+    L.run(d)
+    close(out, ref, 1e-6, 'blur fwd')
+    cot = g(2, 3, H, H, seed=2)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    cd = cot.to(DEV)
+    dx = torch.empty_like(xd)
+    d.x, d.y, d.backward = cd.data_ptr(), dx.data_ptr(), 1
+    L.run(d)
+    close(dx, gx, 1e-6, 'blur adjoint')
+
+
 def test_plan_replay_matches_direct_calls():
     N, H, Cin, Cout = 2, 8, 16, 16
     x = nhwc(g(N, Cin, H, H, seed=1))
