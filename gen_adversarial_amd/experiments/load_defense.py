@@ -4,7 +4,8 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `interpolation_alphas`, `alpha_attenuation`, `initial_noise_eps`, `gaussian_blur_input`), sets `args.image_size`,
 `args.attacks` and attaches `defense_model.get_purified`.
 
-Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only) and 'ours' (NVAE purifier), with the
+Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only), 'ablation' (noise / blur) and 'ours'
+(NVAE purifier), with the
 reference's attack set (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
 Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
 """
@@ -14,6 +15,7 @@ import yaml
 
 from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
+from ..defenses.ablations.models import GaussianBlurDefenseModel, GaussianNoiseDefenseModel
 from ..defenses.ours.models import CelebaIdentityClassifier, NVAEDefenseModel
 from ..defenses.wrappers import EoTWrapper
 
@@ -43,6 +45,13 @@ def load(args: Namespace):
     if args.defense_type in ('base', 'trades'):
         defense_model = base_classifier
         defense_model.get_purified = lambda x: x
+    elif args.defense_type == 'ablation':
+        if d_params.type == 'noise':
+            defense_model = GaussianNoiseDefenseModel(base_classifier, 2. if args.experiment == 'ids' else 4.)
+        else:
+            defense_model = GaussianBlurDefenseModel(base_classifier)
+        defense_model = EoTWrapper(defense_model, args.eot_steps)
+        defense_model.get_purified = lambda x: defense_model.model.purify(x)
     elif args.defense_type == 'ours':
         defense_model = hl_instance(base_classifier, d_params.autoencoder_path, d_params.interpolation_alphas,
                                     d_params.alpha_attenuation, d_params.initial_noise_eps,

@@ -173,3 +173,35 @@ def test_base_classifier_path(setup, tmp_path):
     assert clf.get_purified(x) is x
     with pytest.raises(NotImplementedError):
         load(Namespace(config=args.config, experiment='gender', defense_type='ours', eot_steps=1, device=DEV))
+
+
+def test_ablation_defenders_and_alpha_objective(setup, tmp_path):
+    """defense_type 'ablation' (configs/ablation_{noise,blur}_ids.yaml) and the alpha-learning objective."""
+    from gen_adversarial_amd.experiments.alpha_learning.common_utils import AlphaEvaluator, get_cosine_alphas, random_search
+    args, model, ck, vsd, _ = setup
+    cpath = yaml.safe_load(open(args.config))
+    x = torch.rand(2, *RES, generator=torch.Generator().manual_seed(5))
+    for kind in ('noise', 'blur'):
+        with open(tmp_path / f'{kind}.yaml', 'w') as f:
+            yaml.safe_dump({'classifier_path': cpath['classifier_path'], 'type': kind}, f)
+        a, m = load(Namespace(config=str(tmp_path / f'{kind}.yaml'), experiment='ids', defense_type='ablation', eot_steps=2, device=DEV))
+        p = m.get_purified(x.to(DEV))
+        assert p.shape == x.shape and 0 <= p.min().item() and p.max().item() <= 1
+        if kind == 'blur':
+            assert (p.cpu() - D.apply_gaussian_blur(x)).abs().max().item() < 1e-5
+            ref = D.classifier_call(vsd, build_vgg_spec(100, 16), D.apply_gaussian_blur(x))
+            assert (m.model(x.to(DEV)).cpu() - ref).abs().max().item() < 2e-4
+        else:
+            assert abs((p.cpu() - x).flatten(1).norm(dim=1).max().item() - 2.0) < 0.2      # L2 = eps before the clamp
+        xg = x[:1].to(DEV).requires_grad_(True)
+        (g,) = torch.autograd.grad(m(xg)[0, 0], [xg])
+        assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert get_cosine_alphas(4)[-1] == pytest.approx(1.0)
+    ev_args = Namespace(classifier_type='vgg-11', classifier_path=cpath['classifier_path'],
+                        autoencoder_path=cpath['autoencoder_path'], initial_alphas=[0.] * 6, eot_steps=2)
+    imgs = torch.rand(5, *RES)
+    ev = AlphaEvaluator(ev_args, DEV, images=imgs, labels=torch.zeros(5, dtype=torch.long), batch_images=2)
+    acc = ev.objective_function(torch.full((6,), 0.5))
+    assert 0.0 <= acc <= 1.0
+    al, ac = random_search(ev, 2, seed=1)
+    assert al.shape == (2, 6) and ac.shape == (2, 1)
