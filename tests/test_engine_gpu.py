@@ -206,3 +206,71 @@ def test_blur_and_noise_preprocessing_against_oracle():
     torch.cuda.synchronize()
     assert _err(eng.purified, purified) < TOL and _err(eng.logits, logits) < TOL
     assert _err(eng.dx, gx) < TOL * max(1.0, gx.abs().max().item())
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_robust_accuracy_delta_vs_oracle_under_pgd(precision):
+    """BASELINE.json metric, second half: robust-accuracy of the HIP path vs the CPU oracle on the SAME images and the
+    SAME noise draws, under PGD-Linf (eps 8/255, 6 steps, EoT 4).  Per-image verdicts must agree (delta = 0 here;
+    the bar is +-0.1 %) and the adversarial trajectories must stay within the parity tolerance."""
+    from oracle import defender_oracle as D
+    cfg = {'initial_channels': 8, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 2, 'num_scales': 2,
+           'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
+           'num_latent_per_group': 4, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+    res = (3, 32, 32)
+    spec = build_spec(cfg, res)
+    sd = init_nvae_state_dict(cfg, res, 21)
+    vspec = build_vgg_spec(10, 16)
+    vsd = init_vgg_state_dict(10, 16, 22)
+    B, eot, steps, eps_ball, alpha = 6, 4, 6, 8.0 / 255.0, 2.0 / 255.0
+    rows = B * eot
+    alphas = [0.7 * i / (len(spec.groups) - 1) for i in range(len(spec.groups))]
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.rand(B, *res, generator=gen)
+    draws = [[torch.randn(rows, 4, gs.res, gs.res, generator=gen) for gs in spec.groups] for _ in range(steps + 2)]
+    noise = torch.randn(rows, *res, generator=gen)
+
+    def oracle_logits(x, eps):
+        lg, _ = D.nvae_defender(sd, spec, vsd, vspec, x.repeat_interleave(eot, dim=0), alphas, eps, noise, 0.0)
+        return lg.view(B, eot, -1).mean(dim=1)
+
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=eot, alphas=alphas, device=DEV, precision=precision)
+
+    def hip_logits(x, eps):
+        eng.x_in.copy_(x.to(DEV))
+        for b, e in zip(eng.eps, eps):
+            b.copy_(e.to(DEV))
+        eng.forward()
+        return eng.logits.view(B, eot, -1).mean(dim=1)
+
+    with torch.no_grad():
+        labels = oracle_logits(x0, draws[0]).argmax(dim=1)
+    assert torch.equal(hip_logits(x0, draws[0]).argmax(dim=1).cpu(), labels)
+
+    xa_o, xa_h = x0.clone(), x0.clone()
+    for s in range(steps):
+        xo = xa_o.clone().requires_grad_(True)
+        loss = torch.nn.functional.cross_entropy(oracle_logits(xo, draws[1 + s]), labels, reduction='sum')
+        (g_o,) = torch.autograd.grad(loss, [xo])
+        lh = hip_logits(xa_h, draws[1 + s])
+        p = torch.softmax(lh, dim=1)
+        p[torch.arange(B), labels.to(DEV)] -= 1.0
+        eng.dlogits.view(B, eot, -1).copy_((p / eot).unsqueeze(1).expand(-1, eot, -1))
+        eng.backward()
+        g_h = eng.dx.cpu()
+        # compare raw gradients where the sign is not on a knife edge, then take the same kind of step on each path
+        rel = (g_h - g_o).abs().max().item() / max(g_o.abs().max().item(), 1e-12)
+        assert rel < 5e-2, rel                                    # max-pool near-ties can move isolated elements
+        xa_o = torch.min(torch.max(xa_o + alpha * g_o.sign(), x0 - eps_ball), x0 + eps_ball).clamp(0, 1)
+        xa_h = torch.min(torch.max(xa_h + alpha * g_h.sign(), x0 - eps_ball), x0 + eps_ball).clamp(0, 1)
+    with torch.no_grad():
+        robust_o = oracle_logits(xa_o, draws[steps + 1]).argmax(dim=1) == labels
+        robust_h_on_o = hip_logits(xa_o, draws[steps + 1]).argmax(dim=1).cpu() == labels
+        robust_h = hip_logits(xa_h, draws[steps + 1]).argmax(dim=1).cpu() == labels
+    # same adversarial images -> same verdicts; own trajectories -> same robust accuracy
+    assert torch.equal(robust_h_on_o, robust_o)
+    frac_same_sign = ((xa_h - xa_o).abs() < 1e-6).float().mean().item()
+    print(f'[{precision}] robust-acc oracle {robust_o.float().mean():.3f} hip {robust_h.float().mean():.3f}; '
+          f'adv pixels identical: {frac_same_sign:.4f}')
+    assert abs(robust_h.float().mean().item() - robust_o.float().mean().item()) <= 1.0 / B + 1e-6
+    assert frac_same_sign > 0.97
