@@ -119,7 +119,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -144,6 +144,12 @@ def _load():
     lib.ga_plan_time.restype = C.c_int
     lib.ga_plan_profile.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(f32)]
     lib.ga_plan_profile.restype = C.c_int
+    lib.ga_graph_capture.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ga_graph_capture.restype = C.c_int
+    lib.ga_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ga_graph_launch.restype = C.c_int
+    lib.ga_graph_destroy.argtypes = [C.c_void_p]
+    lib.ga_graph_destroy.restype = C.c_int
     lib.ga_split_bf16.argtypes = [fp, fp, fp, C.c_long, C.c_void_p]
     lib.ga_split_bf16.restype = C.c_int
     lib.ga_last_hip_error.restype = C.c_char_p
@@ -223,6 +229,22 @@ class Plan:
         rc = lib.ga_plan_run(first, end - start, stream, C.byref(failed))
         if rc != 0:
             check(rc, f'plan op #{start + failed.value} ({self.names[start + failed.value]})')
+
+    def capture(self, stream: int):
+        """capture one replay into a HIP graph (stream must not be the NULL stream); returns an opaque handle"""
+        if self._arr is None:
+            self.finalize()
+        h = C.c_void_p()
+        check(lib.ga_graph_capture(self._arr, len(self.descs), stream, C.byref(h)), 'ga_graph_capture')
+        return h
+
+    @staticmethod
+    def launch_graph(handle, stream: int):
+        check(lib.ga_graph_launch(handle, stream), 'ga_graph_launch')
+
+    @staticmethod
+    def destroy_graph(handle):
+        lib.ga_graph_destroy(handle)
 
     def profile(self, stream: int = 0):
         """per-op device milliseconds of one replay."""

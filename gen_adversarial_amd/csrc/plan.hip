@@ -95,6 +95,47 @@ extern "C" int ga_plan_profile(const ga_op* ops, int n, void* stream_, float* pe
     return rc;
 }
 
+// ---- HIP graphs: one replay of a plan captured into an executable graph (the plan only enqueues kernels on one stream,
+//      all pointers are baked into the descriptors, so the capture is a pure kernel chain).  The stream must not be the
+//      NULL stream (capture is illegal there) and the plan must have run eagerly once (first launches set function
+//      attributes).  Launching the graph costs one host call instead of ~700.
+struct ga_graph_t { hipGraph_t graph; hipGraphExec_t exec; };
+
+extern "C" int ga_graph_capture(const ga_op* ops, int n, void* stream_, void** out) {
+    if (!ops || n <= 0 || !out || !stream_) return GA_E_BADARG;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    ga::clear_stale_error();
+    if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { ga::g_last_err = hipGetLastError(); return GA_E_LAUNCH; }
+    const int rc = ga_plan_run(ops, n, stream_, nullptr);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(stream, &graph);
+    if (rc != GA_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) { ga::g_last_err = e; return GA_E_LAUNCH; }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (e2 != hipSuccess) { hipGraphDestroy(graph); ga::g_last_err = e2; return GA_E_LAUNCH; }
+    ga_graph_t* g = new ga_graph_t{graph, exec};
+    *out = g;
+    return GA_OK;
+}
+
+extern "C" int ga_graph_launch(void* graph, void* stream_) {
+    if (!graph) return GA_E_BADARG;
+    ga_graph_t* g = reinterpret_cast<ga_graph_t*>(graph);
+    const hipError_t e = hipGraphLaunch(g->exec, reinterpret_cast<hipStream_t>(stream_));
+    if (e != hipSuccess) { ga::g_last_err = e; return GA_E_LAUNCH; }
+    return GA_OK;
+}
+
+extern "C" int ga_graph_destroy(void* graph) {
+    if (!graph) return GA_E_BADARG;
+    ga_graph_t* g = reinterpret_cast<ga_graph_t*>(graph);
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    delete g;
+    return GA_OK;
+}
+
 extern "C" const char* ga_last_hip_error(void) { return hipGetErrorString(ga::g_last_err); }
 extern "C" int ga_abi_version(void) { return 1; }
 extern "C" unsigned long ga_sizeof_op(void) { return sizeof(ga_op); }

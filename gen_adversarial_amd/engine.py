@@ -713,14 +713,47 @@ class Engine:
             d.alpha, d.one_minus_alpha = alphas[idx], 1.0 - alphas[idx]
         self.fwd.finalize()
         self.bwd.finalize()
+        if getattr(self, '_g_fwd', None) is not None:
+            self.enable_graphs()                            # descriptors changed: re-capture
 
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ---- HIP graphs: the ~700-launch plans become one graph launch each (host cost matters at EoT-32 row counts)
+    def enable_graphs(self):
+        """capture forward and backward on a side stream after one eager warm-up; invalidated by set_alphas/tuning"""
+        if self.dry_run:
+            raise RuntimeError('dry-run engine')
+        self.disable_graphs()
+        self._side = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self.fwd.run(cur.cuda_stream)                       # eager warm-up (sets kernel attributes)
+        if self.need_backward:
+            self.bwd.run(cur.cuda_stream)
+        self._side.wait_stream(cur)
+        self._g_fwd = self.fwd.capture(self._side.cuda_stream)
+        self._g_bwd = self.bwd.capture(self._side.cuda_stream) if self.need_backward else None
+        cur.wait_stream(self._side)
+
+    def disable_graphs(self):
+        for h in (getattr(self, '_g_fwd', None), getattr(self, '_g_bwd', None)):
+            if h is not None:
+                L.Plan.destroy_graph(h)
+        self._g_fwd = self._g_bwd = None
+
+    def _launch_graph(self, handle):
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        L.Plan.launch_graph(handle, self._side.cuda_stream)
+        cur.wait_stream(self._side)
+
     def forward(self):
         if self.dry_run:
             raise RuntimeError('dry-run engine: plans were built for validation only')
-        self.fwd.run(self.stream())
+        if getattr(self, '_g_fwd', None) is not None:
+            self._launch_graph(self._g_fwd)
+        else:
+            self.fwd.run(self.stream())
 
     def backward(self, from_logits: bool = True, from_purified: bool = False):
         """Backward-to-input of the last forward.  Cotangents are read from `self.dlogits` (rows x classes) when
@@ -732,7 +765,10 @@ class Engine:
         if self.dpurified is not None and not from_purified:
             self.dpurified.zero_()
         if from_logits:
-            self.bwd.run(self.stream())
+            if getattr(self, '_g_bwd', None) is not None:
+                self._launch_graph(self._g_bwd)
+            else:
+                self.bwd.run(self.stream())
         else:
             if not self.has_nvae:
                 raise RuntimeError('classifier-only engine: backward starts from the logits')

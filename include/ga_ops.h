@@ -238,6 +238,12 @@ int ga_plan_run(const ga_op* ops, int n, void* stream, int* failed_index);
  * and when conv_ms != NULL also the summed duration of the GA_OP_CONV launches (per-op events). */
 int ga_plan_time(const ga_op* ops, int n, void* stream, int iters, float* total_ms, float* conv_ms, long* conv_launches);
 
+/* HIP graphs: capture one replay of a plan on `stream` (not the NULL stream; the plan must have run eagerly once) into
+ * an executable graph, launch it with one host call, destroy it.  The descriptors' pointers are baked in. */
+int ga_graph_capture(const ga_op* ops, int n, void* stream, void** graph_out);
+int ga_graph_launch(void* graph, void* stream);
+int ga_graph_destroy(void* graph);
+
 /* per-op device time (ms) of one replay: per_op_ms[n] written */
 int ga_plan_profile(const ga_op* ops, int n, void* stream, float* per_op_ms);
 

@@ -274,3 +274,31 @@ def test_robust_accuracy_delta_vs_oracle_under_pgd(precision):
           f'adv pixels identical: {frac_same_sign:.4f}')
     assert abs(robust_h.float().mean().item() - robust_o.float().mean().item()) <= 1.0 / B + 1e-6
     assert frac_same_sign > 0.97
+
+
+def test_hip_graph_replay_is_bitwise_identical(golden_cases):
+    g = golden_cases['A_cos07']
+    x = _t(g['x'])
+    eng = _setup(g, rows=x.shape[0], rep=1, precision='bf16x3')
+    eng.x_in.copy_(x.to(DEV))
+    for i, e in enumerate(eng.eps):
+        e.copy_(_t(g[f'eps_{i}']).to(DEV))
+    cot = _t(g['cotangent']).to(DEV)
+    eng.forward()
+    eng.dlogits.view_as(eng.logits).copy_(cot)
+    eng.backward()
+    torch.cuda.synchronize()
+    l0, p0, d0 = eng.logits.clone(), eng.purified.clone(), eng.dx.clone()
+    eng.enable_graphs()
+    for _ in range(2):
+        eng.logits.zero_(); eng.dx.zero_()
+        eng.forward()
+        eng.dlogits.view_as(eng.logits).copy_(cot)
+        eng.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.logits, l0) and torch.equal(eng.purified, p0) and torch.equal(eng.dx, d0)
+    eng.set_alphas([0.0] * len(eng.alphas))                 # re-captures
+    eng.forward()
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.logits, l0)
+    eng.disable_graphs()
