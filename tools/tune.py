@@ -13,6 +13,7 @@ eng.forward(); eng.dlogits.normal_(); eng.backward(); torch.cuda.synchronize()
 s = eng.stream()
 f0, fc0, _ = eng.fwd.time(s, iters=3, per_conv=True); b0, bc0, _ = eng.bwd.time(s, iters=3, per_conv=True)
 print(f'before: fwd {f0:.2f} (conv {fc0:.2f})  bwd {b0:.2f} (conv {bc0:.2f})', flush=True)
-cache = eng.autotune(cache={}, reps=5, save=out, verbose=True)
+fresh = len(sys.argv) > 3 and sys.argv[3] == 'fresh'
+cache = eng.autotune(cache={} if fresh else None, reps=5, save=out, verbose=True)     # default: add missing shapes
 f1, fc1, _ = eng.fwd.time(s, iters=3, per_conv=True); b1, bc1, _ = eng.bwd.time(s, iters=3, per_conv=True)
 print(f'after : fwd {f1:.2f} (conv {fc1:.2f})  bwd {b1:.2f} (conv {bc1:.2f})  entries {len(cache)}')
