@@ -40,7 +40,7 @@ def conv_algorithmic_flops(plan):
     return total
 
 
-def build_model(device, rows, rep, seed=0, precision='bf16x3'):
+def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False):
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, init_nvae_state_dict
     from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
@@ -51,7 +51,8 @@ def build_model(device, rows, rep, seed=0, precision='bf16x3'):
     vspec = build_vgg_spec(100, 1)
     vsd = init_vgg_state_dict(100, 1, seed + 1)
     eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=rows, rep=rep, alphas=alphas,
-                 temperature=0.6, noise_eps=float(y['initial_noise_eps']), device=device, precision=precision)
+                 temperature=0.6, noise_eps=float(y['initial_noise_eps']), device=device, precision=precision,
+                 share_encoder=share_encoder)
     return eng, (sd, vsd, vspec, alphas)
 
 
@@ -119,6 +120,9 @@ def main():
     ap.add_argument('--rows', type=int, default=256)
     ap.add_argument('--eot', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--share-encoder', action='store_true',
+                    help='run the (deterministic) encoder once per image instead of once per EoT replica; identical '
+                         'results when initial_noise_eps == 0.  Off by default: the headline number is the literal path')
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl',
                     help='collective backend; gloo (CPU tensors) only to rehearse N>1 on a box with fewer GPUs than ranks')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default='bf16x3',
@@ -147,7 +151,7 @@ def main():
     coll_dev = device if args.backend == 'nccl' else 'cpu'
 
     log(f'rank {rank}/{world}: building weights + engine ({args.rows} rows)')
-    eng, model = build_model(device, args.rows, args.eot, seed=0, precision=args.precision)
+    eng, model = build_model(device, args.rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
     log(f'engine ready: {eng.bytes / 1e9:.1f} GB activations, {len(eng.fwd)} fwd + {len(eng.bwd)} bwd ops')
     g = torch.Generator(device=device).manual_seed(1234 + rank)
     x = torch.rand(args.rows // args.eot, 3, 64, 64, device=device, generator=g)
@@ -211,7 +215,7 @@ def main():
             'config': {'workload': 'configs[1]: NVAE purify + VGG-11, 64x64, PGD-Linf step (fwd + input-grad), '
                                    f'{args.rows} rows/GPU = {args.rows // args.eot} images x EoT {args.eot}, '
                                    'alphas ours_cosine_no_preprocessing_ids.yaml x0.7, assumed NVAE config (C=32, 3x8 groups, 20 latents)',
-                       'rows_per_gpu': args.rows, 'eot': args.eot, 'images_per_step': args.rows // args.eot * world,
+                       'rows_per_gpu': args.rows, 'eot': args.eot, 'encoder_shared_by_eot_replicas': bool(eng.share_encoder), 'images_per_step': args.rows // args.eot * world,
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
                          'kernel': 'ga::conv_bf3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, 'libga_ops.so')
 
 GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU = 0, 1, 2, 3
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
- GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR) = range(1, 13)
+ GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR, GA_OP_REP_SUM) = range(1, 14)
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -39,7 +39,7 @@ class ConvDesc(C.Structure):
                 ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
                 ('splits', i32), ('ws', fp), ('ws_floats', C.c_long),
                 ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('_reserved', C.c_uint),
-                ('w_hi', fp), ('w_lo', fp)]
+                ('w_hi', fp), ('w_lo', fp), ('addend_rep', i32), ('_reserved2', i32)]
 
 
 class DwDesc(C.Structure):
@@ -72,7 +72,8 @@ class SamplerDesc(C.Structure):
     _fields_ = [('mu_q', fp), ('ldq', i32), ('p', fp), ('ldp', i32), ('eps', fp), ('eps_nchw', i32),
                 ('z', fp), ('dz', fp), ('dmu_q', fp), ('dp', fp),
                 ('N', i32), ('h', i32), ('w', i32), ('NL', i32),
-                ('alpha', f32), ('one_minus_alpha', f32), ('temp', f32), ('backward', i32)]
+                ('alpha', f32), ('one_minus_alpha', f32), ('temp', f32), ('backward', i32),
+                ('q_rep', i32), ('dmu_q_rows', fp)]
 
 
 class DmlDesc(C.Structure):
@@ -99,10 +100,14 @@ class BlurDesc(C.Structure):
     _fields_ = [('x', fp), ('y', fp), ('taps', fp), ('planes', i32), ('H', i32), ('W', i32), ('k', i32), ('backward', i32)]
 
 
+class RepSumDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('rows', C.c_long), ('inner', C.c_long), ('rep', i32), ('accumulate', i32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [('conv', ConvDesc), ('dw', DwDesc), ('red', ReduceDesc), ('se', SeExciteDesc), ('app', SeApplyDesc),
                 ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
-                ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc)]
+                ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc), ('rs', RepSumDesc)]
 
 
 class Op(C.Structure):
@@ -111,15 +116,15 @@ class Op(C.Structure):
 
 _KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_OP_SE_EXCITE: 'se',
                GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
-               GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur'}
+               GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur', GA_OP_REP_SUM: 'rs'}
 _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
               SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
               DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY,
-              BlurDesc: GA_OP_BLUR}
+              BlurDesc: GA_OP_BLUR, RepSumDesc: GA_OP_REP_SUM}
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -144,6 +149,8 @@ def _load():
     lib.ga_plan_time.restype = C.c_int
     lib.ga_plan_profile.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(f32)]
     lib.ga_plan_profile.restype = C.c_int
+    lib.ga_rep_sum.argtypes = [fp, fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p]
+    lib.ga_rep_sum.restype = C.c_int
     lib.ga_graph_capture.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.ga_graph_capture.restype = C.c_int
     lib.ga_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -189,6 +196,9 @@ def run(desc, stream: int = 0):
     """Launch one op directly through its own C entry point."""
     if isinstance(desc, AxpbyDesc):
         check(lib.ga_axpby(desc.x, desc.y, desc.n, desc.alpha, desc.beta, stream), 'ga_axpby')
+        return
+    if isinstance(desc, RepSumDesc):
+        check(lib.ga_rep_sum(desc.x, desc.y, desc.rows, desc.inner, desc.rep, desc.accumulate, stream), 'ga_rep_sum')
         return
     name = _DIRECT[type(desc)]
     check(getattr(lib, name)(C.byref(desc), stream), name)

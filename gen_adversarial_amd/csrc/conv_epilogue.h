@@ -20,7 +20,8 @@ __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, co
         for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
     }
     if (d.addend) {
-        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        if (d.addend_rep > 1) am = (size_t)((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
         v += *reinterpret_cast<const floatx4*>(d.addend + am * d.ldadd + co);
     }
     if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + (size_t)m * d.ldadd2 + co);
@@ -36,7 +37,8 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
         v *= act_bwd_fast(u, d.dact_act) * ds;
     }
     if (d.addend) {
-        const size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
+        if (d.addend_rep > 1) am = (size_t)((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
         v += d.addend[am * d.ldadd + co];
     }
     if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
@@ -106,6 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                     for (int k = 0; k < NB; ++k) {
                         size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
                         if (d.addend_bcast_n) m = m % HoWo;
+                        if (d.addend_rep > 1) m = ((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
                         a1[k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
                     }
                 }

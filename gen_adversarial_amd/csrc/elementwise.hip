@@ -243,7 +243,8 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % d.NL); const long pix = i / d.NL;            // pix = n*hw + p
         const int n = (int)(pix / hw), p = (int)(pix % hw);
-        const float mq = d.mu_q[pix * d.ldq + c];
+        const long qpix = d.q_rep > 1 ? (long)(n / d.q_rep) * hw + p : pix;
+        const float mq = d.mu_q[qpix * d.ldq + c];
         const float mp = d.p ? d.p[pix * d.ldp + c] : 0.f;
         const float ls = d.p ? d.p[pix * d.ldp + d.NL + c] : 0.f;
         const float e = d.eps_nchw ? d.eps[((size_t)n * d.NL + c) * hw + p] : d.eps[i];
@@ -256,7 +257,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
         } else {
             const float dz = d.dz[i];
             const float denc = om * dz * dsoftclamp5(mp + mq);
-            d.dmu_q[pix * d.ldq + c] = denc;
+            if (d.q_rep > 1) d.dmu_q_rows[i] = denc; else d.dmu_q[pix * d.ldq + c] = denc;
             if (d.dp) {
                 d.dp[pix * d.ldp + c] = denc + a * dz * dsoftclamp5(mp);
                 d.dp[pix * d.ldp + d.NL + c] = a * dz * e * sig * dsoftclamp5(ls);
@@ -479,6 +480,16 @@ __global__ void __launch_bounds__(256) gauss_blur_kernel(const ga_blur_desc d) {
     }
 }
 
+__global__ void __launch_bounds__(256) rep_sum_kernel(const float* x, float* y, const long total, const long inner, const int rep,
+                                                        const int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / inner, j = i - b * inner;
+        float acc = accumulate ? y[i] : 0.f;
+        for (int r = 0; r < rep; ++r) acc += x[(b * rep + r) * inner + j];
+        y[i] = acc;
+    }
+}
+
 __global__ void __launch_bounds__(256) axpby_kernel(const float* x, float* y, const long n, const float a, const float b) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
@@ -551,7 +562,8 @@ extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
     if (!d || !d->mu_q || !d->eps || d->N <= 0 || d->h <= 0 || d->w <= 0 || d->NL <= 0) return GA_E_BADARG;
     if (d->ldq < d->NL || (d->p && d->ldp < 2 * d->NL)) return GA_E_BADARG;
     if (!d->backward && !d->z) return GA_E_BADARG;
-    if (d->backward && (!d->dz || !d->dmu_q || (d->p && !d->dp))) return GA_E_BADARG;
+    if (d->backward && (!d->dz || (d->q_rep > 1 ? !d->dmu_q_rows : !d->dmu_q) || (d->p && !d->dp))) return GA_E_BADARG;
+    if (d->q_rep > 1 && d->N % d->q_rep) return GA_E_BADARG;
     const long total = (long)d->N * d->h * d->w * d->NL;
     hipLaunchKernelGGL(sampler_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();
@@ -603,6 +615,14 @@ extern "C" int ga_gauss_blur(const ga_blur_desc* d, void* s) {
     const size_t lds = ((size_t)2 * d->H * d->W + d->k) * sizeof(float);
     if (lds > 64 * 1024) return GA_E_UNSUPPORTED;            // planes up to ~90 x 90; larger images are a next row
     hipLaunchKernelGGL(gauss_blur_kernel, dim3(d->planes), dim3(256), lds, (hipStream_t)s, *d);
+    return check_launch();
+}
+
+extern "C" int ga_rep_sum(const float* x, float* y, long rows, long inner, int rep, int accumulate, void* s) {
+    ga::clear_stale_error();
+    if (!x || !y || rows <= 0 || inner <= 0 || rep <= 0 || rows % rep) return GA_E_BADARG;
+    const long total = rows / rep * inner;
+    hipLaunchKernelGGL(rep_sum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, x, y, total, inner, rep, accumulate);
     return check_launch();
 }
 

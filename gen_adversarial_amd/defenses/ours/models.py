@@ -42,6 +42,7 @@ class NVAEDefenseModel(MLVGMDefenseModel, torch.nn.Module):
         return Engine(ae.state_dict, ae.config, ae.resolution, clf.state_dict, clf.spec, rows=rows, rep=rep,
                       alphas=self.interpolation_alphas, temperature=self.temperature,
                       noise_eps=self.eps if with_noise else 0.0, blur=self.blur_input and with_noise,
+                      share_encoder=True,      # EoT replicas share the encoder pass whenever no input noise is drawn
                       device=self.device, store=self._store)
 
 

@@ -99,7 +99,8 @@ class Engine:
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
-                 store: Optional[WeightStore] = None, precision: str = 'bf16x3', blur: bool = False):
+                 store: Optional[WeightStore] = None, precision: str = 'bf16x3', blur: bool = False,
+                 share_encoder: bool = False):
         if rows % rep:
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.device = torch.device(device)
@@ -122,6 +123,12 @@ class Engine:
         self.temperature = float(temperature)
         self.noise_eps = float(noise_eps)
         self.blur = bool(blur)
+        # EoT replicas of one image are identical until randomness enters.  Without input noise the whole encoder
+        # (pre-processing + encoder tower + encoder_0 + sampler_0:0, ~57 % of the FLOPs) sees `rep` identical rows per
+        # image: with share_encoder it runs once per IMAGE and its feature maps are read by all replicas of the decoder
+        # (gradients summed over the replicas).  Same numbers as the literal x.repeat(eot) path, row for row.
+        self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0 and nvae_sd is not None
+        self.enc_rows = rows // rep if self.share_encoder else rows
         self.need_backward = need_backward
         self.bytes = 0
         self.acts = {}                       # name -> Act (debugging / tests)
@@ -359,17 +366,19 @@ class Engine:
                 self.bwd.add(b, 'gauss_blur^T')
             self._bwd_steps.append(bwd_blur)
 
-        x0 = Act(self, R, H, H, 3, 'x0')
+        R0 = self.enc_rows                       # rows entering the network (images when the encoder is shared)
+        rep0 = 1 if self.share_encoder else self.rep
+        x0 = Act(self, R0, H, H, 3, 'x0')
         io = L.ImageIoDesc()
         io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
-        io.N, io.C, io.H, io.W, io.rep, io.backward = R, 3, H, H, self.rep, 0
+        io.N, io.C, io.H, io.W, io.rep, io.backward = R0, 3, H, H, rep0, 0
         self.fwd.add(io, 'image_in')
 
         def bwd_image():
             b = L.ImageIoDesc()
             b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef)
             b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(dx_dst)
-            b.N, b.C, b.H, b.W, b.rep, b.backward = R, 3, H, H, self.rep, 1
+            b.N, b.C, b.H, b.W, b.rep, b.backward = R0, 3, H, H, rep0, 1
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
@@ -470,7 +479,9 @@ class Engine:
         stem = self.devd('stem', lambda: F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'))
         norm = self.devd('norm05', lambda: {'two': torch.full((3,), 2.0), 'mone': torch.full((3,), -1.0)})
         two, mone = norm['two'], norm['mone']
-        x = Act(self, R, H, H, spec.base_channels, 'stem')
+        RE = self.enc_rows                        # encoder rows: R, or R/rep when the encoder is shared by the replicas
+        erep = self.rep if self.share_encoder else 1
+        x = Act(self, RE, H, H, spec.base_channels, 'stem')
         self.conv(self.fwd, 'stem', x0.t, stem['w'], x.t, bias=stem['b'], K=3, pad=1, pro_scale=two, pro_shift=mone)
         stem_out = x
 
@@ -495,13 +506,13 @@ class Engine:
         C0 = spec.enc0_channels
         g0 = spec.groups[0]
         enc0 = self.devd('encoder_0', lambda: F.fold_wn_conv(nvae_sd, 'encoder_0.1'))
-        e0 = Act(self, R, g0.res, g0.res, C0, 'enc0')
+        e0 = Act(self, RE, g0.res, g0.res, C0, 'enc0')
         self.conv(self.fwd, 'encoder_0', x_top.t, enc0['w'], e0.t, bias=enc0['b'], K=1, pro_act=L.GA_ACT_ELU)
         s00 = self.devd('enc_sampler_0:0', lambda: F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)))
-        muq0 = Act(self, R, g0.res, g0.res, NL, 'mu_q0')
+        muq0 = Act(self, RE, g0.res, g0.res, NL, 'mu_q0')
         self.conv(self.fwd, 'enc_sampler_0:0', e0.t, s00['w'], muq0.t, bias=s00['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
         z = Act(self, R, g0.res, g0.res, NL, 'z0')
-        self._sampler_fwd('sample_0:0', muq0, None, self.eps[0], z, self.alphas[0])
+        self._sampler_fwd('sample_0:0', muq0, None, self.eps[0], z, self.alphas[0], q_rep=erep)
 
         # ---- combiner_0:0 on cat[const_prior, z0]: the prior half is row-independent -> folded into a broadcast addend
         def fold_comb0():
@@ -518,7 +529,7 @@ class Engine:
 
         def bwd_group0():
             self.grad_conv('combiner_0:0^T', comb0_out.g, wz_bwd, z0, K=1)
-            self._sampler_bwd('sample_0:0^T', muq0, None, self.eps[0], z0, self.alphas[0], None)
+            self._sampler_bwd('sample_0:0^T', muq0, None, self.eps[0], z0, self.alphas[0], None, q_rep=erep)
             self.grad_conv('enc_sampler_0:0^T', muq0.g, s00['w_bwd'], e0, K=3, pad=1, dact_x=e0.t, dact_act=L.GA_ACT_ELU)
             self.grad_conv('encoder_0^T', e0.g, enc0['w_bwd'], x_top, K=1, dact_x=x_top.t, dact_act=L.GA_ACT_ELU)
         group0_bwd = bwd_group0     # must run after every decoder-side use of the encoder features: registered below
@@ -531,7 +542,7 @@ class Engine:
             if gs.dec_cells:
                 for cell in gs.dec_cells:
                     x = self.dec_cell(cell, x)
-                x = self._latent_group(gs, x, stash[f'{gs.s}:{gs.g}'])
+                x = self._latent_group(gs, x, stash[f'{gs.s}:{gs.g}'], erep)
             if gs.g == spec.groups_per_scale[gs.s] - 1 and gs.s in spec.dec_up_cells:
                 x = self.dec_cell(spec.dec_up_cells[gs.s], x)
 
@@ -564,7 +575,7 @@ class Engine:
         return img
 
     # ------------------------------------------------------------------------------------------------ latents
-    def _sampler_fwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float):
+    def _sampler_fwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float, q_rep: int = 1):
         d = L.SamplerDesc()
         d.mu_q, d.ldq = _ptr(muq.t), muq.c
         if p is not None:
@@ -572,23 +583,41 @@ class Engine:
         d.eps, d.eps_nchw, d.z = _ptr(eps), 1, _ptr(z.t)
         d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 0
+        d.q_rep = q_rep
         self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.fwd.add(d, name)
 
-    def _sampler_bwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float, dp: Optional[Act]):
+    def _sampler_bwd(self, name, muq: Act, p: Optional[Act], eps, z: Act, alpha: float, dp: Optional[Act], q_rep: int = 1):
         d = L.SamplerDesc()
         d.mu_q, d.ldq = _ptr(muq.t), muq.c
         if p is not None:
             d.p, d.ldp, d.dp = _ptr(p.t), p.c, _ptr(p.g)
             p.g_written = True
-        d.eps, d.eps_nchw, d.dz, d.dmu_q = _ptr(eps), 1, _ptr(z.g), _ptr(muq.g)
-        muq.g_written = True
+        d.eps, d.eps_nchw, d.dz = _ptr(eps), 1, _ptr(z.g)
+        d.q_rep = q_rep
+        rows_grad = None
+        if q_rep > 1:
+            rows_grad = self.scratch((z.n, z.h, z.w, z.c), 'dmu_q_rows')
+            d.dmu_q_rows = _ptr(rows_grad)
+        else:
+            d.dmu_q = _ptr(muq.g)
         d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 1
         self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.bwd.add(d, name)
+        if q_rep > 1:
+            self.rep_sum(name + '.rep_sum', rows_grad, muq, q_rep)
+        muq.g_written = True
 
-    def _latent_group(self, gs, x: Act, enc_feat: Act) -> Act:
+    def rep_sum(self, name, x_rows: torch.Tensor, target: Act, rep: int):
+        """target.g (+)= sum over the `rep` replicas of x_rows (gradient of a tensor shared by the EoT replicas)"""
+        r = L.RepSumDesc()
+        r.x, r.y, r.rows, r.inner, r.rep = _ptr(x_rows), _ptr(target.g), x_rows.shape[0], x_rows[0].numel(), rep
+        r.accumulate = int(target.g_written)
+        self.bwd.add(r, name)
+        target.g_written = True
+
+    def _latent_group(self, gs, x: Act, enc_feat: Act, enc_rep: int = 1) -> Act:
         """models.py:236-257 for one latent group: encoder/decoder parameters, interpolation, combiner."""
         sd, R, NL, C, r = self.nvae_sd, self.rows, self.spec.num_latent, gs.channels, gs.res
         key = f'{gs.s}:{gs.g}'
@@ -606,7 +635,8 @@ class Engine:
         eps = self.eps[gs.latent_idx]
 
         ec = Act(self, R, r, r, C, f'ec_{key}')
-        self.conv(self.fwd, f'enc_combiner_{key}', x.t, ec_w['w'], ec.t, bias=ec_w['b'], K=1, addend=enc_feat.t)
+        d_ec = self.conv(self.fwd, f'enc_combiner_{key}', x.t, ec_w['w'], ec.t, bias=ec_w['b'], K=1, addend=enc_feat.t)
+        d_ec.addend_rep = enc_rep
         muq = Act(self, R, r, r, NL, f'mu_q_{key}')
         self.conv(self.fwd, f'enc_sampler_{key}', ec.t, es_w['w'], muq.t, bias=es_w['b'], K=3, pad=1)
         pp = Act(self, R, r, r, 2 * NL, f'p_{key}')
@@ -623,7 +653,10 @@ class Engine:
             self.grad_conv(f'dec_sampler_{key}^T', pp.g, ds_w['w_bwd'], x, K=1, dact_x=x.t, dact_act=L.GA_ACT_ELU)
             self.grad_conv(f'enc_sampler_{key}^T', muq.g, es_w['w_bwd'], ec, K=3, pad=1)
             self.grad_conv(f'enc_combiner_{key}^T', ec.g, ec_w['w_bwd'], x, K=1)
-            # the additive encoder feature receives d(ec) unchanged
+            # the additive encoder feature receives d(ec) unchanged (summed over the replicas that share it)
+            if enc_rep > 1:
+                self.rep_sum(f'enc_feat_{key}.grad', ec.g, enc_feat, enc_rep)
+                return
             if enc_feat.g_written:
                 a = L.AxpbyDesc()
                 a.x, a.y, a.n, a.alpha, a.beta = _ptr(ec.g), _ptr(enc_feat.g), ec.g.numel(), 1.0, 1.0

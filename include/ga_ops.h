@@ -79,6 +79,9 @@ typedef struct ga_conv_desc {
     const void* w_hi;                      /* optional: w split as bf16 hi + lo, both [Cout][KH*KW*(C1+C2)] (ga_split_bf16). */
     const void* w_lo;                      /* When given and the shape allows, the contraction runs as 3 bf16 MFMAs per
                                               product on the bf16 matrix cores (~2e-5 relative), else exact fp32 MFMA. */
+    int addend_rep;                        /* > 1: addend has N/addend_rep rows, row n reads addend row n / addend_rep
+                                              (EoT replicas sharing one encoder feature map) */
+    int _reserved2;
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
@@ -161,6 +164,10 @@ typedef struct ga_sampler_desc {
     const float* dz;   /* bwd in */
     float* dmu_q; float* dp;   /* bwd out */
     int N, h, w, NL; float alpha, one_minus_alpha, temp; int backward;   /* one_minus_alpha = (float)(1.0 - alpha_double) */
+    int q_rep;         /* > 1: mu_q (and dmu_q) have N/q_rep rows; row n uses row n / q_rep.  In the backward pass dmu_q is then
+                          NOT written (several rows map to one): the caller gets d(mu_q) per row in `dmu_q_rows` [N,h,w,NL]
+                          and reduces it with ga_rep_sum */
+    float* dmu_q_rows;
 } ga_sampler_desc;
 int ga_sampler_mix(const ga_sampler_desc* d, void* stream);
 
@@ -212,6 +219,10 @@ int ga_gauss_blur(const ga_blur_desc* d, void* stream);
 /* w[n] fp32 -> hi[n], lo[n] bf16 with hi = bf16(w), lo = bf16(w - hi) (weight preparation for w_hi / w_lo) */
 int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream);
 
+/* y[b, i] (+)= sum_{r < rep} x[b*rep + r, i]   (x: [rows][inner], y: [rows/rep][inner]; fixed order, deterministic):
+ * gradient of a tensor shared by `rep` EoT replicas */
+int ga_rep_sum(const float* x, float* y, long rows, long inner, int rep, int accumulate, void* stream);
+
 /* y = alpha*x + beta*y over n floats */
 int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* stream);
 
@@ -220,15 +231,16 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
  * ------------------------------------------------------------------------------------------------------------------ */
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
-                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12 };
+                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
+typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
     int kind;
     int _pad;
     union {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
-        ga_axpby_desc ax; ga_blur_desc blur;
+        ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -35,14 +35,14 @@ def _err(a, b):
 PRECISIONS = [('fp32', TOL), ('bf16x3', TOL_SPEC)]
 
 
-def _setup(g, rows, rep, precision='fp32'):
+def _setup(g, rows, rep, precision='fp32', share_encoder=False):
     cfg, res = golden_cfg(g)
     sd = init_nvae_state_dict(cfg, res, int(g['nvae_seed']))
     vspec = build_vgg_spec(int(g['n_classes']), int(g['width_div']))
     vsd = init_vgg_state_dict(int(g['n_classes']), int(g['width_div']), int(g['vgg_seed']))
     alphas = [float(a) * float(g['attenuation']) for a in g['alphas']]
     eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, temperature=0.6,
-                 noise_eps=float(g['noise_eps']), device=DEV, precision=precision)
+                 noise_eps=float(g['noise_eps']), device=DEV, precision=precision, share_encoder=share_encoder)
     return eng
 
 
@@ -75,11 +75,15 @@ def test_defender_matches_reference_golden(name, golden_cases, precision, tol):
     assert e_p < tol and e_l < tol and e_g < tol * max(1.0, gmax) and tol <= TOL_SPEC
 
 
+@pytest.mark.parametrize('share', [False, True])
 @pytest.mark.parametrize('name', CASES)
-def test_eot_ce_gradient_matches_reference_golden(name, golden_cases):
+def test_eot_ce_gradient_matches_reference_golden(name, golden_cases, share):
+    """EoTWrapper + CE gradient; `share`: the encoder runs once per image and is shared by the EoT replicas (only takes
+    effect without input noise — the engine falls back to the literal path otherwise)."""
     g = golden_cases[name]
     eot = int(g['eot_steps'])
-    eng = _setup(g, rows=eot, rep=eot)
+    eng = _setup(g, rows=eot, rep=eot, share_encoder=share)
+    assert eng.share_encoder == (share and float(g['noise_eps']) == 0.0)
     eng.x_in.copy_(_t(g['x'][:1]).to(DEV))
     for i, e in enumerate(eng.eps):
         e.copy_(_t(g[f'eot_eps_{i}']).to(DEV))
@@ -119,8 +123,9 @@ def test_multiple_backwards_per_forward_and_determinism(golden_cases):
     assert _err(g2, 2 * g1) < 1e-6
 
 
+@pytest.mark.parametrize('share', [False, True])
 @pytest.mark.parametrize('precision,tol', PRECISIONS)
-def test_against_oracle_on_fresh_inputs(precision, tol):
+def test_against_oracle_on_fresh_inputs(precision, tol, share):
     """oracle (CPU) vs HIP on a mid-size config with 32-multiple channels (vectorised paths, every tile shape).
     The input-gradient is checked in two legs: through the NVAE alone (cotangent on the purified image: smooth, strict
     tolerance) and through the classifier, whose 2x2 max-pools make the gradient discontinuous at near-ties — a
@@ -149,7 +154,9 @@ def test_against_oracle_on_fresh_inputs(precision, tol):
     cot = torch.randn(logits.shape, generator=gen)
     (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
 
-    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV, precision=precision)
+    eng = Engine(sd, cfg, res, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV, precision=precision,
+                 share_encoder=share)
+    assert eng.share_encoder == share and eng.enc_rows == (rows // rep if share else rows)
     eng.x_in.copy_(imgs.to(DEV))
     for b, e in zip(eng.eps, eps):
         b.copy_(e.to(DEV))

@@ -460,6 +460,27 @@ def test_gauss_blur_forward_and_adjoint(H, k):
     close(dx, gx, 1e-6, 'blur adjoint')
 
 
+def test_rep_sum_and_shared_addend():
+    rows, rep, inner = 12, 4, 40
+    x = g(rows, inner, seed=1).to(DEV)
+    y = g(rows // rep, inner, seed=2).to(DEV)
+    ref = y + x.view(rows // rep, rep, inner).sum(dim=1)
+    r = L.RepSumDesc()
+    r.x, r.y, r.rows, r.inner, r.rep, r.accumulate = x.data_ptr(), y.data_ptr(), rows, inner, rep, 1
+    L.run(r)
+    close(y, ref, 1e-6, 'rep_sum accumulate')
+    r.accumulate = 0
+    L.run(r)
+    close(y, x.view(rows // rep, rep, inner).sum(dim=1), 1e-6, 'rep_sum')
+    # conv whose addend has one row per group of `rep` output rows
+    N, H, Cin, Cout = 6, 4, 16, 8
+    xx, w, add = g(N, Cin, H, H, seed=3), g(Cout, Cin, 1, 1, seed=4, scale=0.2), g(N // 3, Cout, H, H, seed=5)
+    refc = F.conv2d(xx, w) + add.repeat_interleave(3, dim=0)
+    yy = torch.empty(N, H, H, Cout, device=DEV)
+    run_conv(nhwc(xx), fwd_w(w), yy, 1, addend=nhwc(add), ldadd=Cout, addend_rep=3)
+    close(nchw(yy), refc, 2e-5, 'addend_rep')
+
+
 def test_plan_replay_matches_direct_calls():
     N, H, Cin, Cout = 2, 8, 16, 16
     x = nhwc(g(N, Cin, H, H, seed=1))
