@@ -520,6 +520,8 @@ class Engine:
             prior = nvae_sd['const_prior'].double()[0]                                           # [C0,h,w]
             pc = torch.einsum('oc,chw->hwo', wfull[:, :C0], prior) + \
                 nvae_sd['decoder_combiners.combiner_0:0.conv.bias'].double()
+            if spec.num_nf_cells:            # flow of this group = z - c (folding.nf_constant_shift): fold W_z c into the addend
+                pc = pc - wfull[:, C0:] @ F.nf_constant_shift(nvae_sd, '0:0', spec.num_nf_cells, NL)
             return {'pc': pc.float().unsqueeze(0), 'wz': wfull[:, C0:].float(), 'wz_bwd': wfull[:, C0:].t().float()}
         c0w = self.devd('combiner_0:0', fold_comb0)
         pc, wz, wz_bwd = c0w['pc'], c0w['wz'], c0w['wz_bwd']                                     # pc: [1,h,w,C0]
@@ -627,7 +629,10 @@ class Engine:
 
         def fold_comb():
             cb = F.wn_weight64(sd, f'decoder_combiners.combiner_{key}.conv')[:, :, 0, 0]         # [C, C+NL]
-            return {'w': cb.float(), 'b': sd[f'decoder_combiners.combiner_{key}.conv.bias'],
+            bias = sd[f'decoder_combiners.combiner_{key}.conv.bias'].double()
+            if self.spec.num_nf_cells:       # the group's flow is z - c: combiner(cat[x, z - c]) = ... - W_z c
+                bias = bias - cb[:, C:] @ F.nf_constant_shift(sd, key, self.spec.num_nf_cells, NL)
+            return {'w': cb.float(), 'b': bias.float(),
                     'x_bwd': cb[:, :C].t().float(), 'z_bwd': cb[:, C:].t().float()}
         cbw = self.devd(f'combiner_{key}', fold_comb)
         cb_w, cb_b, cbx_bwd, cbz_bwd = cbw['w'], cbw['b'], cbw['x_bwd'], cbw['z_bwd']

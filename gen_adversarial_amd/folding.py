@@ -155,3 +155,21 @@ def fold_vgg_head(sd: SD, feat_channels: int, feat_hw: int, chunk: int = 2048) -
     w3 = sd['model.classifier.3.weight']
     return {'w_head': out, 'w_head_bwd': out.t().contiguous(), 'b_head': f32(t),
             'w_out': f32(w3), 'w_out_bwd': f32(w3.t()), 'b_out': f32(sd['model.classifier.3.bias'])}
+
+
+def nf_constant_shift(sd: SD, key: str, num_nf_cells: int, num_latent: int) -> torch.Tensor:
+    """
+    Normalizing-flow cells on the purification path (models.py:209-210, 253-254): NFCell(z) = z - layers(z)
+    (architecture.py:238-239).  The last conv of `layers` is a 1x1 MaskedConv2d built with zero_diag=False, whose mask
+    keeps (1*1)//2 + 0 = 0 taps (architecture.py:20-23): its output is its bias for every input, so each cell subtracts a
+    per-channel constant and a whole group's flow is  z -> z - c,  c = sum of those biases.  Returned as float64 [NL];
+    raises if a checkpoint's masks do not have that form (a genuine flow would need its own kernels).
+    """
+    c = torch.zeros(num_latent, dtype=torch.float64)
+    for n in range(num_nf_cells):
+        for cell in ('cell1', 'cell2'):
+            p = f'nf_cells.nf_{key}.{n}.{cell}.layers.4'
+            if float(sd[f'{p}.mask'].abs().sum()) != 0.0:
+                raise NotImplementedError('normalizing-flow cell with a non-empty 1x1 mask: not built')
+            c += sd[f'{p}.bias'].double()
+    return c

@@ -85,6 +85,7 @@ class NVAESpec:
     cells_per_group: int
     num_latent: int
     num_mixtures: int
+    num_nf_cells: int          # NFBlocks per latent group (0 = none; model.py:58-59, 216-221)
     pre_cells: List[EncCellSpec]
     # encoder tower in execution order: list of (kind, payload)
     #   ('cell', EncCellSpec) | ('stash', 's:g') | ('down', EncCellSpec)
@@ -104,9 +105,6 @@ class NVAESpec:
 
 def build_spec(cfg: dict, resolution: Tuple[int, int, int]) -> NVAESpec:
     """Replays the channel bookkeeping of AutoEncoder.__init__ (model.py:27-85)."""
-    if cfg.get('num_nf_cells', None) is not None:
-        raise NotImplementedError('normalizing-flow cells (model.py:216-221) are not on the built path yet')
-
     img_c, res, _ = resolution
     C = cfg['initial_channels']
     n_blocks = cfg['num_pre-post_process_blocks']
@@ -181,7 +179,8 @@ def build_spec(cfg: dict, resolution: Tuple[int, int, int]) -> NVAESpec:
 
     logits_in = C * dmult
     logits_out = nmix + nmix * 3 * img_c                                   # model.py:302-315
-    return NVAESpec(cfg, img_c, res, C, n_scales, gps, cpg, NL, nmix, pre_cells, enc_program, enc0_channels,
+    return NVAESpec(cfg, img_c, res, C, n_scales, gps, cpg, NL, nmix, int(cfg.get('num_nf_cells') or 0), pre_cells,
+                    enc_program, enc0_channels,
                     prior_shape, groups, dec_up, post_cells, logits_in, logits_out)
 
 
@@ -258,6 +257,28 @@ def _dec_cell(sd, rng, cell: DecCellSpec):
     _se(sd, rng, f'{p}.residual.{o + 9}', cell.cout)
 
 
+def nf_mask(shape, mirror: bool, zero_diag: bool) -> torch.Tensor:
+    """MaskedConv2d mask (architecture.py:16-26): keep the first (kh*kw)//2 + zero_diag taps in row-major order (the
+    last ones when mirrored).  NOTE: for a 1x1 kernel with zero_diag=False this keeps NOTHING — the last conv of every
+    NFCell (architecture.py:233-234) therefore outputs its bias only."""
+    co, ci, kh, kw = shape
+    m = torch.ones(co, ci, kh * kw)
+    half = (kh * kw) // 2 + int(zero_diag)
+    m[:, :, half:] = 0
+    if mirror:
+        m = torch.flip(m, dims=(2,))
+    return m.view(co, ci, kh, kw)
+
+
+def _nf_cell(sd, rng, prefix, nl, mirror):
+    hid = nl * 6
+    for idx, (co, ci, k, zd) in ((0, (hid, nl, 3, True)), (2, (hid, 1, 5, False)), (4, (nl, hid, 1, False))):
+        fan = ci * k * k
+        sd[f'{prefix}.layers.{idx}.weight'] = rng.normal((co, ci, k, k), std=1.0 / np.sqrt(fan))
+        sd[f'{prefix}.layers.{idx}.bias'] = rng.normal((co,), std=0.05)
+        sd[f'{prefix}.layers.{idx}.mask'] = nf_mask((co, ci, k, k), mirror, zd)
+
+
 def init_nvae_state_dict(cfg: dict, resolution: Tuple[int, int, int], seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     """
     Random weights in the exact state-dict layout of the reference AutoEncoder
@@ -285,6 +306,10 @@ def init_nvae_state_dict(cfg: dict, resolution: Tuple[int, int, int], seed: int 
         _wn_conv(sd, rng, f'enc_sampler.sampler_{gs.s}:{gs.g}', 2 * NL, gs.channels, 3, gain=0.5)
         if not (gs.s == 0 and gs.g == 0):
             _wn_conv(sd, rng, f'dec_sampler.sampler_{gs.s}:{gs.g}.1', 2 * NL, gs.channels, 1, gain=0.5)
+    for gs in spec.groups:
+        for n in range(spec.num_nf_cells):
+            _nf_cell(sd, rng, f'nf_cells.nf_{gs.s}:{gs.g}.{n}.cell1', NL, False)
+            _nf_cell(sd, rng, f'nf_cells.nf_{gs.s}:{gs.g}.{n}.cell2', NL, True)
     for gs in spec.groups:
         for cell in gs.dec_cells:
             _dec_cell(sd, rng, cell)

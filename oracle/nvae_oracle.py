@@ -93,6 +93,24 @@ def dec_cell(sd: SD, cell: DecCellSpec, x):
     return skip + 0.1 * r
 
 
+def nf_cell(sd: SD, prefix: str, z, hidden: int):
+    """NFCell.forward — architecture.py:221-239 with MaskedConv2d (:9-34): weights multiplied by their masks."""
+    def w(i):
+        return sd[f'{prefix}.layers.{i}.weight'] * sd[f'{prefix}.layers.{i}.mask']
+    h = F.elu(F.conv2d(z, w(0), sd[f'{prefix}.layers.0.bias'], padding=1))
+    h = F.elu(F.conv2d(h, w(2), sd[f'{prefix}.layers.2.bias'], padding=2, groups=hidden))
+    h = F.conv2d(h, w(4), sd[f'{prefix}.layers.4.bias'])
+    return z - h
+
+
+def nf_blocks(sd: SD, spec: NVAESpec, key: str, z):
+    """nf_cells['nf_s:g'] = Sequential of NFBlocks (cell1 then mirrored cell2) — model.py:216-221, architecture.py:242-253."""
+    for n in range(spec.num_nf_cells):
+        z = nf_cell(sd, f'nf_cells.nf_{key}.{n}.cell1', z, spec.num_latent * 6)
+        z = nf_cell(sd, f'nf_cells.nf_{key}.{n}.cell2', z, spec.num_latent * 6)
+    return z
+
+
 def soft_clamp(x, n: float = 5.0):
     """distributions.py:20-29."""
     return torch.tanh(x / n) * n
@@ -155,6 +173,7 @@ def nvae_purify(sd: SD, spec: NVAESpec, batch: torch.Tensor, alphas: Sequence[fl
     dec_mu, dec_sigma = normal_mu_sigma(torch.zeros_like(mu_q), torch.zeros_like(mu_q), temperature)
     a = float(alphas[g0.latent_idx])
     z = (1 - a) * enc_mu + a * (eps[0] * dec_sigma + dec_mu)                 # models.py:206 (+ Normal.sample :43-45)
+    z = nf_blocks(sd, spec, '0:0', z)                                        # models.py:209-210
     latents.append(z)
 
     x = sd['const_prior'].expand(b, -1, -1, -1)                              # models.py:215
@@ -172,6 +191,7 @@ def nvae_purify(sd: SD, spec: NVAESpec, batch: torch.Tensor, alphas: Sequence[fl
             dec_mu, dec_sigma = normal_mu_sigma(mu_p, log_sig_p, temperature)   # models.py:247
             a = float(alphas[gs.latent_idx])
             z = (1 - a) * enc_mu + a * (eps[gs.latent_idx] * dec_sigma + dec_mu)   # models.py:249-250
+            z = nf_blocks(sd, spec, key, z)                                  # models.py:253-254
             latents.append(z)
             x = wn_conv(sd, f'decoder_combiners.combiner_{key}.conv', torch.cat([x, z], dim=1))   # models.py:257
         if gs.g == spec.groups_per_scale[gs.s] - 1 and gs.s in spec.dec_up_cells:

@@ -29,4 +29,4 @@ def golden_cfg(g):
 
 @pytest.fixture(scope='session')
 def golden_cases():
-    return {n: load_golden(f'nvae_{n}.npz') for n in ('A_cos07', 'A_zero_noise2', 'B_adaptive')}
+    return {n: load_golden(f'nvae_{n}.npz') for n in ('A_cos07', 'A_zero_noise2', 'B_adaptive', 'A_nf2')}

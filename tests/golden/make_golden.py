@@ -28,8 +28,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
 sys.dont_write_bytecode = True
-sys.path.insert(0, REPO)
-sys.path.insert(1, REF)
+sys.path.insert(0, REF)        # the reference's `src` package must win over the repo's import-compat `src/` shim
+sys.path.insert(1, REPO)
 
 
 def install_shims():
@@ -305,8 +305,12 @@ def run_modules():
     print('modules done')
 
 
+CFG_NF = dict(CFG_A, **{'num_nf_cells': 2})
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    run_case('A_nf2', CFG_NF, RES_A, rows=2, alphas=cosine_alphas(4), attenuation=0.7, noise_eps=0.0, eot=2)
     run_case('A_cos07', CFG_A, RES_A, rows=3, alphas=cosine_alphas(4), attenuation=0.7, noise_eps=0.0, eot=4)
     run_case('A_zero_noise2', CFG_A, RES_A, rows=2, alphas=[0.0] * 4, attenuation=1.0, noise_eps=2.0, eot=2)
     nB = len(build_spec(CFG_B, RES_B).groups)

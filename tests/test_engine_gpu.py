@@ -21,7 +21,7 @@ from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   #
 DEV = 'cuda:0'
 TOL_SPEC = 1e-3
 TOL = 2e-4
-CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive']
+CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive', 'A_nf2']
 
 
 def _t(a):

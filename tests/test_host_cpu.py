@@ -167,3 +167,26 @@ def test_oracle_noise_and_blur_helpers():
     assert D.blur_kernel_size(64) == 15 and D.blur_kernel_size(256) == 255   # abstract_models.py:153-156
     b = D.apply_gaussian_blur(torch.rand(1, 3, 64, 64))
     assert b.shape == (1, 3, 64, 64)
+
+
+def test_nf_cells_reduce_to_a_constant_shift():
+    """The fold the engine uses for normalizing-flow cells (folding.nf_constant_shift) equals the oracle's masked-conv
+    evaluation of architecture.py:221-253 on random latents."""
+    import torch
+    from gen_adversarial_amd import folding
+    from gen_adversarial_amd.nvae_spec import build_spec, init_nvae_state_dict
+    from oracle import nvae_oracle
+    cfg = {'initial_channels': 8, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 1, 'num_scales': 2,
+           'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
+           'num_latent_per_group': 4, 'num_logistic_mixtures': 3, 'num_nf_cells': 3}
+    spec = build_spec(cfg, (3, 16, 16))
+    sd = init_nvae_state_dict(cfg, (3, 16, 16), 5)
+    for gs in spec.groups:
+        key = f'{gs.s}:{gs.g}'
+        z = torch.randn(2, 4, 4, 4)
+        c = folding.nf_constant_shift(sd, key, 3, 4)
+        torch.testing.assert_close(nvae_oracle.nf_blocks(sd, spec, key, z), z - c.float().view(1, -1, 1, 1),
+                                   rtol=0, atol=1e-6)
+    sd['nf_cells.nf_0:0.0.cell1.layers.4.mask'].fill_(1.0)
+    with pytest.raises(NotImplementedError):
+        folding.nf_constant_shift(sd, '0:0', 3, 4)

@@ -15,7 +15,7 @@ from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
 from oracle import defender_oracle as D
 from oracle import nvae_oracle as O
 
-CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive']
+CASES = ['A_cos07', 'A_zero_noise2', 'B_adaptive', 'A_nf2']
 TOL = 1e-5
 
 
