@@ -1,12 +1,14 @@
 """
 bench.py — purification-under-attack throughput on MI355X (contract: see the task statement / DESIGN.md §Measurement).
 
-One "step" = one white-box attack iteration over one batch of defender rows:
-  EoT repeat -> NVAE purify (encode + decode) -> VGG-11 classify -> EoT-mean logits -> CE loss
+One "step" = one white-box attack iteration over one batch of images:
+  EoT repeat (x32) -> NVAE purify (encode + decode) -> VGG-11 classify -> EoT-mean logits -> CE loss
   -> backward-to-input through classifier and purifier -> PGD-Linf sign step + projection,
 with fresh N(0,1) latent noise every step, synthetic images already resident in HBM.
-Workload at N=1: BASELINE.json configs[1] — NVAE purify, CelebA-64 shapes, 256 rows (8 images x EoT 32), fp32,
-alphas of configs/ours_cosine_no_preprocessing_ids.yaml x 0.7, assumed NVAE config of SURVEY.md §6.
+Workload at N=1: BASELINE.json configs[1] — NVAE purify, CelebA-64 shapes, bs = 256 images (x EoT 32 = 8192 defender
+rows), fp32-class arithmetic, alphas of configs/ours_cosine_no_preprocessing_ids.yaml x 0.7, assumed NVAE config of
+SURVEY.md §6.  The 8192 rows of a step run as chunks of --chunk-rows rows (activations of a 512-row chunk: 67 GB),
+alternating over --streams engines on their own HIP streams so that one chunk's kernel tails overlap the other's.
 N>1: the same batch per rank (weak scaling, images are independent), one RCCL all-gather of accuracy counters.
 """
 import argparse
@@ -57,27 +59,69 @@ def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=Fal
 
 
 class AttackStep:
-    """PGD-Linf iteration on the engine (eps 8/255, step 2/255)."""
+    """PGD-Linf iteration (eps 8/255, step 2/255) on `images`, processed as chunks of eng.rows // rep images that
+    alternate over the engines (one HIP stream each; engines share the folded weights)."""
 
-    def __init__(self, eng, labels, x_orig, eps=8.0 / 255.0, step=2.0 / 255.0):
-        self.eng, self.labels, self.x_orig, self.eps, self.step_size = eng, labels, x_orig, eps, step
+    def __init__(self, engines, streams, labels, x_orig, eps=8.0 / 255.0, step=2.0 / 255.0):
+        self.engines, self.streams = engines, streams
+        self.labels, self.x_orig, self.eps, self.step_size = labels, x_orig, eps, step
         self.x_adv = x_orig.clone()
-        self.rep = eng.rep
+        self.rep = engines[0].rep
+        self.per = engines[0].rows // self.rep                    # images per chunk
+        assert x_orig.shape[0] % self.per == 0
+        self.logits = torch.zeros(x_orig.shape[0], engines[0].logits.shape[-1], device=x_orig.device)
 
-    def __call__(self):
-        eng = self.eng
-        eng.x_in.copy_(self.x_adv)
+    def chunk(self, eng, lo, hi):
+        eng.x_in.copy_(self.x_adv[lo:hi])
         for e in eng.eps:
             e.normal_()
         eng.forward()
         logits = eng.logits.view(-1, self.rep, eng.logits.shape[-1]).mean(dim=1)          # EoT mean
         p = torch.softmax(logits, dim=1)
-        p[torch.arange(p.shape[0], device=p.device), self.labels] -= 1.0                   # d CE / d mean-logits
+        p[torch.arange(p.shape[0], device=p.device), self.labels[lo:hi]] -= 1.0           # d CE / d mean-logits
         eng.dlogits.view(-1, self.rep, p.shape[-1]).copy_((p / self.rep).unsqueeze(1).expand(-1, self.rep, -1))
         eng.backward()
-        nxt = self.x_adv + self.step_size * eng.dx.sign()
-        self.x_adv = torch.min(torch.max(nxt, self.x_orig - self.eps), self.x_orig + self.eps).clamp_(0.0, 1.0)
-        return logits
+        nxt = self.x_adv[lo:hi] + self.step_size * eng.dx.sign()
+        xo = self.x_orig[lo:hi]
+        self.x_adv[lo:hi] = torch.min(torch.max(nxt, xo - self.eps), xo + self.eps).clamp_(0.0, 1.0)
+        self.logits[lo:hi] = logits
+
+    def forward_only(self):
+        """clean EoT-mean logits of x_adv (used once to pick the labels)"""
+        self._run(lambda eng, lo, hi: self._fwd(eng, lo, hi))
+        return self.logits
+
+    def _fwd(self, eng, lo, hi):
+        eng.x_in.copy_(self.x_adv[lo:hi])
+        for e in eng.eps:
+            e.normal_()
+        eng.forward()
+        self.logits[lo:hi] = eng.logits.view(-1, self.rep, eng.logits.shape[-1]).mean(dim=1)
+
+    def _run(self, fn):
+        main = torch.cuda.current_stream()
+        for s in self.streams:
+            s.wait_stream(main)
+        for c in range(self.x_orig.shape[0] // self.per):
+            k = c % len(self.engines)
+            with torch.cuda.stream(self.streams[k]):
+                fn(self.engines[k], c * self.per, (c + 1) * self.per)
+        for s in self.streams:
+            main.wait_stream(s)
+
+    def __call__(self):
+        self._run(self.chunk)
+        return self.logits
+
+
+def clone_engine(eng, model, device, args):
+    """a second engine over the same folded weights (WeightStore) with its own activations, for another stream"""
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION
+    sd, vsd, vspec, alphas = model
+    return Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=eng.rows, rep=eng.rep, alphas=alphas,
+                  temperature=0.6, noise_eps=eng.noise_eps, device=device, precision=args.precision,
+                  share_encoder=args.share_encoder, store=eng.store)
 
 
 def cpu_baseline(model, rows, rep):
@@ -117,8 +161,11 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--rows', type=int, default=256)
+    ap.add_argument('--images', type=int, default=256, help='images per GPU per step (bs of BASELINE.json configs[1])')
     ap.add_argument('--eot', type=int, default=32)
+    ap.add_argument('--chunk-rows', type=int, default=512,
+                    help='defender rows (images x EoT) one plan run processes; a 512-row chunk holds 67 GB of activations')
+    ap.add_argument('--streams', type=int, default=2, help='engines / HIP streams the chunks alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--share-encoder', action='store_true',
                     help='run the (deterministic) encoder once per image instead of once per EoT replica; identical '
@@ -150,18 +197,25 @@ def main():
             dist.init_process_group('gloo', rank=rank, world_size=world)
     coll_dev = device if args.backend == 'nccl' else 'cpu'
 
-    log(f'rank {rank}/{world}: building weights + engine ({args.rows} rows)')
-    eng, model = build_model(device, args.rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
-    log(f'engine ready: {eng.bytes / 1e9:.1f} GB activations, {len(eng.fwd)} fwd + {len(eng.bwd)} bwd ops')
+    if args.chunk_rows % args.eot or (args.images * args.eot) % args.chunk_rows:
+        raise SystemExit('--chunk-rows must be a multiple of --eot and divide images x eot')
+    n_chunks = args.images * args.eot // args.chunk_rows
+    n_eng = max(1, min(args.streams, n_chunks))
+    rows_per_step = args.images * args.eot
+    log(f'rank {rank}/{world}: building weights + {n_eng} engine(s) of {args.chunk_rows} rows')
+    eng, model = build_model(device, args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
+    engines = [eng]
+    for _ in range(n_eng - 1):
+        engines.append(clone_engine(eng, model, device, args))
+    streams = [torch.cuda.Stream(device=device) for _ in engines]
+    log(f'engines ready: {sum(e.bytes for e in engines) / 1e9:.1f} GB activations + weights, {len(eng.fwd)} fwd + {len(eng.bwd)} bwd ops per chunk, '
+        f'{n_chunks} chunks per step')
     g = torch.Generator(device=device).manual_seed(1234 + rank)
-    x = torch.rand(args.rows // args.eot, 3, 64, 64, device=device, generator=g)
+    x = torch.rand(args.images, 3, 64, 64, device=device, generator=g)
     # labels = clean prediction of the defender, so that the attack starts from "correct" 
-    eng.x_in.copy_(x)
-    for e in eng.eps:
-        e.normal_()
-    eng.forward()
-    labels = eng.logits.view(-1, args.eot, eng.logits.shape[-1]).mean(dim=1).argmax(dim=1)
-    step = AttackStep(eng, labels, x)
+    step = AttackStep(engines, streams, None, x)
+    labels = step.forward_only().argmax(dim=1)
+    step.labels = labels
 
     for _ in range(args.warmup):
         step()
@@ -194,7 +248,7 @@ def main():
 
     if rank == 0:
         log(f'timed region: {dt:.3f} s for {args.steps} steps')
-        rows_total = args.rows * world * args.steps
+        rows_total = rows_per_step * world * args.steps
         # ---- roofline of the dominant kernel (conv_mfma_kernel): HIP events on the plan's stream, per launch
         s = eng.stream()
         f_ms, fc_ms, fn = eng.fwd.time(s, iters=1, per_conv=True)
@@ -213,9 +267,12 @@ def main():
             'dtype': 'f32 storage; contractions as 3x bf16 MFMA (hi/lo split), fp32 accumulate' if args.precision == 'bf16x3' else 'f32',
             'data': 'synthetic',
             'config': {'workload': 'configs[1]: NVAE purify + VGG-11, 64x64, PGD-Linf step (fwd + input-grad), '
-                                   f'{args.rows} rows/GPU = {args.rows // args.eot} images x EoT {args.eot}, '
+                                   f'bs {args.images} images/GPU x EoT {args.eot} = {rows_per_step} defender rows per step, '
                                    'alphas ours_cosine_no_preprocessing_ids.yaml x0.7, assumed NVAE config (C=32, 3x8 groups, 20 latents)',
-                       'rows_per_gpu': args.rows, 'eot': args.eot, 'encoder_shared_by_eot_replicas': bool(eng.share_encoder), 'images_per_step': args.rows // args.eot * world,
+                       'images_per_gpu': args.images, 'eot': args.eot, 'rows_per_gpu': rows_per_step,
+                       'chunk_rows': args.chunk_rows, 'streams': n_eng,
+                       'encoder_shared_by_eot_replicas': bool(eng.share_encoder), 'images_per_step': args.images * world,
+                       'images_per_s': args.images * world * args.steps / dt,
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
                          'kernel': 'ga::conv_bf3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
@@ -223,9 +280,11 @@ def main():
                          'peak_note': ('dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-class product; achieved counts '
                                        'algorithmic (1x) flops' if args.precision == 'bf16x3' else 'fp32 MFMA peak'),
                          'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
-                         'launches_per_step': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
-                         'algorithmic_gflop_per_step': flops / 1e9,
-                         'conv_ms_per_step': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms},
+                         'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                         'algorithmic_gflop_per_chunk': flops / 1e9, 'chunks_per_step': n_chunks,
+                         'conv_ms_per_chunk': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms,
+                         'note': 'per-launch durations: HIP events around every conv launch of one chunk (forward + backward '
+                                 'plan) on one stream, right after the timed region'},
             'accuracy_counters': [float(counters[0].item()), float(counters[1].item())],
         }
         if not args.no_cpu_baseline and world == 1:

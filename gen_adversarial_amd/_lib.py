@@ -16,7 +16,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libga_ops.so')
+LIB_PATH = os.environ.get('GA_OPS_LIB') or os.path.join(_HERE, 'libga_ops.so')   # GA_OPS_LIB: debug builds only (make trace)
 
 GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU = 0, 1, 2, 3
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,

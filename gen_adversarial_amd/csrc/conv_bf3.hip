@@ -26,15 +26,32 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
+// -DGA_TRACE (make trace -> libga_ops_trace.so, tools/conv_trace.py): shader-clock stamps of the phases of each workgroup
+#ifdef GA_TRACE
+__device__ unsigned long long ga_trace_buf[8 * 8192];
+#define GA_STAMP(i)                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) {                                      \
+        ga_trace_buf[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                              \
+        if ((i) == 0) ga_trace_buf[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     \
+    }
+#else
+#define GA_STAMP(i)
+#endif
+
 constexpr int BK3 = 32;     // k per LDS stage
 constexpr int LDB = 40;     // bf16 elements per LDS row (32 + 8 pad = 80 B)
 
-// PRO: 0 none, 1 per-channel affine and/or activation, 2 per-(row,channel) affine (+ activation), 3 = SiLU only.
-// DUAL: a second K source (x2) exists.  Both are compile-time so that the steady-state loop body is one basic block:
-// the scheduler can then place the loader's VALU work (prologue + bf16 split of tile t+1) BETWEEN the MFMAs of tile t
-// (sched_group_barrier), instead of two waves per SIMD running their matrix phases and their VALU phases in lockstep.
-template <int WM, int WN, int TM, int TN, int PRO, bool DUAL>
-__global__ void __launch_bounds__(256)
+// AFF: 0 no affine, 1 per-channel scale/shift, 2 per-(row,channel) scale/shift.  ACT: the GA_ACT_* prologue activation.
+// DUAL: a second K source (x2) exists (only without a prologue).  All three are compile-time so that the steady-state
+// loop body is ONE basic block with no calls: the scheduler can then place the loader's VALU work (prologue + bf16
+// split of tile t+1) BETWEEN the MFMAs of tile t (sched_group_barrier).  The lambdas are always_inline for the same
+// reason — left to its heuristics the compiler outlined finish_tile in the larger instances, which put the staging
+// registers in scratch and turned the LDS accesses into flat ones.
+#ifndef GA_MINWG
+#define GA_MINWG 1
+#endif
+template <int WM, int WN, int TM, int TN, int AFF, int ACT, bool DUAL>
+__global__ void __launch_bounds__(256, GA_MINWG)
 conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
                 const int vec_out) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -44,6 +61,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __bf16* lds = reinterpret_cast<__bf16*>(smem);
 
+    GA_STAMP(0)
     int bid;
     {
         const int nb = gridDim.x, orig = blockIdx.x;
@@ -95,20 +113,21 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         baseB[i] = (row < BN && co < d.Cout) ? (co * Ktot + 8 * k8) * 2 : INV;
     }
 
-    floatx4 ra[RA], rs[PRO == 2 ? RA : 1], rt[PRO == 2 ? RA : 1];
+    static_assert(!DUAL || (AFF == 0 && ACT == GA_ACT_NONE), "a dual-source conv has no prologue");
+    floatx4 ra[RA], rs[AFF == 2 ? RA : 1], rt[AFF == 2 ? RA : 1];
     uintx4 rbh[RB], rbl[RB];
     unsigned okmask = 0;
     int cur_c = 0;
 
     int q_tap = 0, q_chunk = 0, q_kh = 0, q_kw = 0;
-    auto seek_tile = [&](const int t) {
+    auto seek_tile = [&](const int t) __attribute__((always_inline)) {
         q_tap = __builtin_amdgcn_readfirstlane(t / nkc);
         q_chunk = __builtin_amdgcn_readfirstlane(t - q_tap * nkc);
         q_kh = __builtin_amdgcn_readfirstlane(q_tap / d.KW);
         q_kw = q_tap - q_kh * d.KW;
     };
 
-    auto issue_tile = [&]() {
+    auto issue_tile = [&]() __attribute__((always_inline)) {
         const int tap = q_tap, c0 = q_chunk * BK3;
         const int kh = q_kh, kw = q_kw;
         if (++q_chunk == nkc) { q_chunk = 0; ++q_tap; if (++q_kw == d.KW) { q_kw = 0; ++q_kh; } }
@@ -146,51 +165,42 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
             rbh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWh, off, soffB, 0);
             rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, off, soffB, 0);
         }
-        if (PRO == 1) {
-            if (d.pro_scale) {          // uniform
-                const int pc = (in_x & cval) ? c : 0;
-                rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
-                rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
-            }
-        } else if (PRO == 2) {
+        if (AFF == 1) {
+            const int pc = cval ? c : 0;
+            rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
+            rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
+        } else if (AFF == 2) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                const size_t po = (in_x && ((okmask >> i) & 1u)) ? (size_t)a_n[i] * d.C1 + c : 0;
+                const size_t po = ((okmask >> i) & 1u) ? (size_t)a_n[i] * d.C1 + c : 0;
                 rs[i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
                 rt[i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
             }
         }
     };
 
-    auto finish_tile = [&](const int buf) {
+    auto finish_tile = [&](const int buf) __attribute__((always_inline)) {
         __bf16* Ah = lds + buf * STAGE;
         __bf16* Al = Ah + BM * LDB;
         __bf16* Bh = Al + BM * LDB;
         __bf16* Bl = Bh + BN * LDB;
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
-        const bool first = cur_c < d.C1;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             floatx4 v = ra[i];
-            if (PRO == 3) {                                  // SiLU, no affine: silu(0) = 0, padded taps stay zero
-                floatx4 pv = v;
+            if (AFF == 2) v = v * rs[i] + rt[i];
+            else if (AFF == 1) v = v * rs[0] + rt[0];
+            if (ACT == GA_ACT_SILU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
-                v = (!DUAL || first) ? pv : v;
-            } else if (PRO != 0) {
-                floatx4 pv = v;
-                if (PRO == 2) pv = pv * rs[i] + rt[i];
-                else if (d.pro_scale) pv = pv * rs[0] + rt[0];
-                if (d.pro_act == GA_ACT_SILU) {
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
+            } else if (ACT == GA_ACT_ELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
-                } else if (d.pro_act != GA_ACT_NONE) {
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;
+            } else if (ACT == GA_ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pv[e] = act_fwd_fast(pv[e], d.pro_act);
-                }
-                v = first ? pv : v;
-                v = (okmask >> i) & 1u ? v : zero;
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (AFF != 0) v = (okmask >> i) & 1u ? v : zero;     // act(0) = 0 for all three: only a shift un-zeroes padding
             const bf16x4 hi = __builtin_convertvector(v, bf16x4);
             const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
             const int o = (r0 + 32 * i) * LDB + 4 * c4;
@@ -222,13 +232,15 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     const int t_end = min(T, t_begin + tper);
 
     const int lrow = lane & 31, lh = lane >> 5;
+    GA_STAMP(1)
     if (t_begin < t_end) {
         seek_tile(t_begin);
         issue_tile();
         finish_tile(0);
     }
     __syncthreads();
-    auto mma_tile = [&](const int buf) {
+    GA_STAMP(2)
+    auto mma_tile = [&](const int buf) __attribute__((always_inline)) {
         const __bf16* Ah = lds + buf * STAGE + (wm * TM * 32 + lrow) * LDB + 8 * lh;
         const __bf16* Al = Ah + BM * LDB;
         const __bf16* Bh = lds + buf * STAGE + 2 * BM * LDB + (wn * TN * 32 + lrow) * LDB + 8 * lh;
@@ -260,13 +272,19 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     // steady state: a next tile exists -> no branch in the body; the staging math of tile t+1 is spread between the
     // MFMAs of tile t (1 MFMA : 4 VALU : 1 DS, the matrix pipe takes 32 cycles per MFMA, a VALU op 4-8)
     constexpr int NMFMA = TM * TN * 3 * (BK3 / 16);
-    auto body = [&](const int buf) {        // MFMAs of the staged tile || split + LDS write of the next one (already loaded)
-        mma_tile(buf);
-        finish_tile(buf ^ 1);
+    // VALU ops of one staged tile: per float4 ~12 for the split, 4 affine, 20 SiLU/ELU, 4 ReLU, 4 padding select
+    constexpr int VOPS = RA * (12 + (AFF ? 8 : 0) + (ACT == GA_ACT_SILU || ACT == GA_ACT_ELU ? 20 : ACT == GA_ACT_RELU ? 4 : 0)) + 8;
+    constexpr int VPM = (VOPS + NMFMA - 1) / NMFMA;
+#ifndef GA_EXP
+#define GA_EXP 0        // trace builds only: bit 0 drops the split + LDS write, 1 the global loads, 2 the barrier, 3 the MFMAs
+#endif
+    auto body = [&](const int buf) __attribute__((always_inline)) {        // MFMAs of the staged tile || split + LDS write of the next one (already loaded)
+        if (!(GA_EXP & 8)) mma_tile(buf);
+        if (!(GA_EXP & 1)) finish_tile(buf ^ 1);
 #pragma unroll
         for (int k = 0; k < NMFMA; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+            __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);    // VALU
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
         }
     };
@@ -277,8 +295,8 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     if (t + 1 < t_end) issue_tile();                    // tile t_begin+1 in flight
     for (; t + 2 < t_end; ++t) {
         body(buf);
-        issue_tile();                                   // tile t+2
-        __syncthreads();
+        if (!(GA_EXP & 2)) issue_tile();                // tile t+2
+        if (!(GA_EXP & 4)) __syncthreads();
         buf ^= 1;
     }
     if (t + 1 < t_end) {
@@ -288,20 +306,35 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     }
     if (t_begin < t_end) mma_tile(buf);
     __syncthreads();        // every wave is done reading the operand tiles before the epilogue reuses the LDS
+    GA_STAMP(3)
 
     conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
+    GA_STAMP(4)
 }
 
-template <int WM, int WN, int TM, int TN, int PRO, bool DUAL>
+template <int WM, int WN, int TM, int TN, int AFF, int ACT, bool DUAL>
 static void launch_bf3_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                             int Ktot, int nkc, int vec_out) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, PRO, DUAL>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, PRO, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+}
+
+// (dual << 8) | (affine kind << 4) | activation — the key of the instantiated prologue variants
+static inline int conv_bf3_mode(const ga_conv_desc& d) {
+    return ((d.C2 > 0 ? 1 : 0) << 8) | ((d.pro_scale ? (d.pro_per_row ? 2 : 1) : 0) << 4) | d.pro_act;
+}
+
+// 1 when conv_bf3 has a kernel for this descriptor's prologue (ga_conv2d falls back to the fp32 kernel otherwise)
+int conv_bf3_supports(const ga_conv_desc& d) {
+    switch (conv_bf3_mode(d)) {
+        case 0x000: case 0x100: case 0x001: case 0x002: case 0x003: case 0x010: case 0x011: case 0x020: case 0x021: return 1;
+        default: return 0;
+    }
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -316,13 +349,18 @@ static int launch_bf3(const ga_conv_desc& d, hipStream_t stream, int vec_out, in
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
-    int pro = d.pro_scale && d.pro_per_row ? 2 : ((d.pro_scale || d.pro_act) ? 1 : 0);
-    if (pro == 1 && !d.pro_scale && d.pro_act == GA_ACT_SILU) pro = 3;
-#define GA_BF3(P, D) launch_bf3_inst<WM, WN, TM, TN, P, D>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out)
-    if (d.C2 > 0) {
-        if (pro == 0) GA_BF3(0, true); else if (pro == 1) GA_BF3(1, true); else if (pro == 2) GA_BF3(2, true); else GA_BF3(3, true);
-    } else {
-        if (pro == 0) GA_BF3(0, false); else if (pro == 1) GA_BF3(1, false); else if (pro == 2) GA_BF3(2, false); else GA_BF3(3, false);
+#define GA_BF3(A, C, D) launch_bf3_inst<WM, WN, TM, TN, A, C, D>(d, stream, grid, lds, tilesN, M, Ctot, Ktot, nkc, vec_out)
+    switch (conv_bf3_mode(d)) {         // the prologue combinations the purification / classifier plans contain
+        case 0x000: GA_BF3(0, GA_ACT_NONE, false); break;
+        case 0x100: GA_BF3(0, GA_ACT_NONE, true); break;
+        case 0x001: GA_BF3(0, GA_ACT_SILU, false); break;
+        case 0x002: GA_BF3(0, GA_ACT_ELU, false); break;
+        case 0x003: GA_BF3(0, GA_ACT_RELU, false); break;
+        case 0x010: GA_BF3(1, GA_ACT_NONE, false); break;
+        case 0x011: GA_BF3(1, GA_ACT_SILU, false); break;
+        case 0x020: GA_BF3(2, GA_ACT_NONE, false); break;
+        case 0x021: GA_BF3(2, GA_ACT_SILU, false); break;
+        default: return GA_E_UNSUPPORTED;
     }
 #undef GA_BF3
     return check_launch();
@@ -332,6 +370,11 @@ static int launch_bf3(const ga_conv_desc& d, hipStream_t stream, int vec_out, in
 int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
     switch (tile) {
         case 1: return launch_bf3<2, 2, 2, 2>(d, stream, vec_out, splits);
+#ifdef GA_TRACE_TILE1_ONLY      // quick experiment builds
+        default: return GA_E_UNSUPPORTED;
+    }
+    switch (tile) {
+#endif
         case 2: return launch_bf3<4, 1, 1, 2>(d, stream, vec_out, splits);
         case 3: return launch_bf3<2, 2, 1, 1>(d, stream, vec_out, splits);
         case 4: return launch_bf3<4, 1, 1, 1>(d, stream, vec_out, splits);
@@ -350,6 +393,12 @@ __global__ void split_bf16_kernel(const float* w, __bf16* hi, __bf16* lo, const 
 }
 
 }  // namespace ga
+
+#ifdef GA_TRACE
+extern "C" int ga_debug_trace_read(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ga::ga_trace_buf), (size_t)n * 8) == hipSuccess ? GA_OK : GA_E_LAUNCH;
+}
+#endif
 
 extern "C" int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream) {
     ga::clear_stale_error();

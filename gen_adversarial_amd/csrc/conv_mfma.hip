@@ -111,14 +111,14 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
     // K-tile cursor kept in scalar registers and advanced incrementally (tiles are issued in order): no integer
     // division in the loop and everything derived from it is provably wave-uniform (buffer descriptors, soffsets).
     int q_tap = 0, q_chunk = 0, q_kh = 0, q_kw = 0;
-    auto seek_tile = [&](const int t) {
+    auto seek_tile = [&](const int t) __attribute__((always_inline)) {
         q_tap = __builtin_amdgcn_readfirstlane(t / nkc);
         q_chunk = __builtin_amdgcn_readfirstlane(t - q_tap * nkc);
         q_kh = __builtin_amdgcn_readfirstlane(q_tap / d.KW);
         q_kw = q_tap - q_kh * d.KW;
     };
 
-    auto issue_tile = [&](const int) {
+    auto issue_tile = [&](const int) __attribute__((always_inline)) {
         const int tap = q_tap, c0 = q_chunk * BK;
         const int kh = q_kh, kw = q_kw;
         if (++q_chunk == nkc) { q_chunk = 0; ++q_tap; if (++q_kw == d.KW) { q_kw = 0; ++q_kh; } }
@@ -255,7 +255,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
         }
     };
 
-    auto finish_tile = [&](const int buf) {
+    auto finish_tile = [&](const int buf) __attribute__((always_inline)) {
         float* Ab = As + buf * BM * LDK;
         float* Bb = Bs + buf * BN * LDK;
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -426,6 +426,7 @@ static int launch_conv(const ga_conv_desc& d, hipStream_t stream, bool vec, int 
 }
 
 int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits);   // conv_bf3.hip
+int conv_bf3_supports(const ga_conv_desc& d);
 
 }  // namespace ga
 
@@ -491,7 +492,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     const int Ctot = d.C1 + d.C2;
     const bool bf3 = d.w_hi && d.w_lo && vec && d.sd == 1 && (d.C2 == 0 || d.C1 % 32 == 0) && (Ctot % 8 == 0) &&
                      d.KH * d.KW <= 32 && k.x_bytes > 0 && k.w_bytes > 0 && (d.C2 == 0 || k.x2_bytes > 0) &&
-                     aligned16(d.w_hi) && aligned16(d.w_lo);
+                     aligned16(d.w_hi) && aligned16(d.w_lo) && conv_bf3_supports(d);
     int rc;
     if (bf3) {
         rc = conv_bf3_dispatch(k, stream, tile, vec_out, splits);

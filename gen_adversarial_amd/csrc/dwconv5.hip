@@ -100,7 +100,7 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
         }
     };
 
-    auto finish = [&](floatx4 v, const size_t o) {
+    auto finish = [&](floatx4 v, const size_t o) __attribute__((always_inline)) {
         if (d.dact_x) {
             const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
             if (d.dact_act == GA_ACT_SILU) {
