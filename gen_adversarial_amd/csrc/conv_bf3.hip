@@ -48,12 +48,12 @@ constexpr int LDB = 40;     // bf16 elements per LDS row (32 + 8 pad = 80 B)
 // reason — left to its heuristics the compiler outlined finish_tile in the larger instances, which put the staging
 // registers in scratch and turned the LDS accesses into flat ones.
 #ifndef GA_MINWG
-#define GA_MINWG 1
+#define GA_MINWG 2      // two workgroups per CU: the register budget is 256 per lane
 #endif
 template <int WM, int WN, int TM, int TN, int AFF, int ACT, bool DUAL>
 __global__ void __launch_bounds__(256, GA_MINWG)
 conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
-                const int vec_out) {
+                const int vec_out, const fastdiv fd_howo, const fastdiv fd_wo) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int RA = BM / 32;
     constexpr int RB = BN >= 64 ? BN / 64 : 1;
@@ -91,14 +91,10 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         unsigned mk = 0;
         int n = -1, h0 = 0, w0 = 0;
         if (m < M) {
-            n = m / HoWo;
-            const int rem = m - n * HoWo, ho = rem / d.Wo, wo = rem - ho * d.Wo;
+            n = fd_div(m, fd_howo);
+            const int rem = m - n * HoWo, ho = fd_div(rem, fd_wo), wo = rem - ho * d.Wo;
             h0 = ho * d.sn - d.pad; w0 = wo * d.sn - d.pad;
-            for (int kh = 0; kh < d.KH; ++kh)
-                for (int kw = 0; kw < d.KW; ++kw) {
-                    const int hi = h0 + kh, wi = w0 + kw;
-                    if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) mk |= 1u << (kh * d.KW + kw);
-                }
+            mk = tap_mask(h0, w0, d.Hi, d.Wi, d.KH, d.KW);
         }
         a_n[i] = n;
         maskA[i] = mk;
@@ -114,10 +110,13 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     }
 
     static_assert(!DUAL || (AFF == 0 && ACT == GA_ACT_NONE), "a dual-source conv has no prologue");
-    floatx4 ra[RA], rs[AFF == 2 ? RA : 1], rt[AFF == 2 ? RA : 1];
-    uintx4 rbh[RB], rbl[RB];
-    unsigned okmask = 0;
-    int cur_c = 0;
+    // staging registers: NSET sets.  With two, the loads of tile t+2 are issued at the START of iteration t (into the set
+    // iteration t-1 drained) and consumed in iteration t+1: a whole iteration of MFMAs hides the L2 latency.  The
+    // per-row-affine variant keeps one set (its scale/shift staging would not fit 256 registers twice).
+    constexpr int NSET = AFF == 2 ? 1 : 2;
+    floatx4 ra[NSET][RA], rs[NSET][AFF == 2 ? RA : 1], rt[NSET][AFF == 2 ? RA : 1];
+    uintx4 rbh[NSET][RB], rbl[NSET][RB];
+    unsigned okmask[NSET] = {};
 
     int q_tap = 0, q_chunk = 0, q_kh = 0, q_kw = 0;
     auto seek_tile = [&](const int t) __attribute__((always_inline)) {
@@ -127,13 +126,12 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         q_kw = q_tap - q_kh * d.KW;
     };
 
-    auto issue_tile = [&]() __attribute__((always_inline)) {
+    auto issue_tile = [&](const int set) __attribute__((always_inline)) {
         const int tap = q_tap, c0 = q_chunk * BK3;
         const int kh = q_kh, kw = q_kw;
         if (++q_chunk == nkc) { q_chunk = 0; ++q_tap; if (++q_kw == d.KW) { q_kw = 0; ++q_kh; } }
         const int c = c0 + 4 * c4;
-        cur_c = c;
-        okmask = 0;
+        okmask[set] = 0;
         const bool in_x = DUAL ? c0 < d.C1 : true;
         const int lim = (in_x ? d.C1 : Ctot) - c0;
         const bool cval = 4 * c4 < lim;
@@ -145,16 +143,16 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
             for (int i = 0; i < RA; ++i) {
                 const bool valid = cval & ((maskA[i] & bit) != 0);
                 const int off = valid ? baseA[i] + delta : INV;
-                okmask |= (valid ? 1u : 0u) << i;
-                ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, soffA, 0));
+                okmask[set] |= (valid ? 1u : 0u) << i;
+                ra[set][i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, soffA, 0));
             }
         } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 const bool valid = cval & ((maskA[i] & bit) != 0);
                 const int off = valid ? baseA2[i] + delta : INV;
-                okmask |= (valid ? 1u : 0u) << i;
-                ra[i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, soffA, 0));
+                okmask[set] |= (valid ? 1u : 0u) << i;
+                ra[set][i] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, soffA, 0));
             }
         }
         const int soffB = (tap * Ctot + c0) * 2;
@@ -162,24 +160,24 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int off = bval ? baseB[i] : INV;
-            rbh[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWh, off, soffB, 0);
-            rbl[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, off, soffB, 0);
+            rbh[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWh, off, soffB, 0);
+            rbl[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, off, soffB, 0);
         }
         if (AFF == 1) {
             const int pc = cval ? c : 0;
-            rs[0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
-            rt[0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
+            rs[set][0] = *reinterpret_cast<const floatx4*>(d.pro_scale + pc);
+            rt[set][0] = *reinterpret_cast<const floatx4*>(d.pro_shift + pc);
         } else if (AFF == 2) {
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
-                const size_t po = ((okmask >> i) & 1u) ? (size_t)a_n[i] * d.C1 + c : 0;
-                rs[i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
-                rt[i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
+                const size_t po = ((okmask[set] >> i) & 1u) ? (size_t)a_n[i] * d.C1 + c : 0;
+                rs[set][i] = *reinterpret_cast<const floatx4*>(d.pro_scale + po);
+                rt[set][i] = *reinterpret_cast<const floatx4*>(d.pro_shift + po);
             }
         }
     };
 
-    auto finish_tile = [&](const int buf) __attribute__((always_inline)) {
+    auto finish_tile = [&](const int set, const int buf) __attribute__((always_inline)) {
         __bf16* Ah = lds + buf * STAGE;
         __bf16* Al = Ah + BM * LDB;
         __bf16* Bh = Al + BM * LDB;
@@ -187,9 +185,9 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            floatx4 v = ra[i];
-            if (AFF == 2) v = v * rs[i] + rt[i];
-            else if (AFF == 1) v = v * rs[0] + rt[0];
+            floatx4 v = ra[set][i];
+            if (AFF == 2) v = v * rs[set][i] + rt[set][i];
+            else if (AFF == 1) v = v * rs[set][0] + rt[set][0];
             if (ACT == GA_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
@@ -200,7 +198,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
             }
-            if (AFF != 0) v = (okmask >> i) & 1u ? v : zero;     // act(0) = 0 for all three: only a shift un-zeroes padding
+            if (AFF != 0) v = (okmask[set] >> i) & 1u ? v : zero;     // act(0) = 0 for all three: only a shift un-zeroes padding
             const bf16x4 hi = __builtin_convertvector(v, bf16x4);
             const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
             const int o = (r0 + 32 * i) * LDB + 4 * c4;
@@ -211,8 +209,8 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         for (int i = 0; i < RB; ++i) {
             const int row = rb0 + 64 * i;
             if (BN >= 64 || row < BN) {
-                *reinterpret_cast<uintx4*>(Bh + row * LDB + 8 * k8) = rbh[i];
-                *reinterpret_cast<uintx4*>(Bl + row * LDB + 8 * k8) = rbl[i];
+                *reinterpret_cast<uintx4*>(Bh + row * LDB + 8 * k8) = rbh[set][i];
+                *reinterpret_cast<uintx4*>(Bl + row * LDB + 8 * k8) = rbl[set][i];
             }
         }
     };
@@ -235,8 +233,9 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     GA_STAMP(1)
     if (t_begin < t_end) {
         seek_tile(t_begin);
-        issue_tile();
-        finish_tile(0);
+        issue_tile(0);
+        if (NSET == 2 && t_begin + 1 < t_end) issue_tile(1);
+        finish_tile(0, 0);
     }
     __syncthreads();
     GA_STAMP(2)
@@ -278,32 +277,31 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 #ifndef GA_EXP
 #define GA_EXP 0        // trace builds only: bit 0 drops the split + LDS write, 1 the global loads, 2 the barrier, 3 the MFMAs
 #endif
-    auto body = [&](const int buf) __attribute__((always_inline)) {        // MFMAs of the staged tile || split + LDS write of the next one (already loaded)
+    // one K step: [issue tile t+2 into the drained set] ; MFMAs of LDS stage `buf` || split + LDS write of tile t+1
+    // (registers of set `cons`) into the other stage ; barrier.  `cons`/`prod` are literals at every call site.
+    auto step = [&](const int buf, const int cons, const int prod, const bool more2) __attribute__((always_inline)) {
+        if (NSET == 2 && more2 && !(GA_EXP & 2)) issue_tile(prod);
         if (!(GA_EXP & 8)) mma_tile(buf);
-        if (!(GA_EXP & 1)) finish_tile(buf ^ 1);
+        if (!(GA_EXP & 1)) finish_tile(cons, buf ^ 1);
 #pragma unroll
         for (int k = 0; k < NMFMA; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
             __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);    // VALU
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
         }
-    };
-    // the loads of tile t+1 are issued one whole iteration before their registers are consumed (right after the
-    // registers are freed by finish_tile), so the interleaved VALU never waits on memory
-    int buf = 0;
-    int t = t_begin;
-    if (t + 1 < t_end) issue_tile();                    // tile t_begin+1 in flight
-    for (; t + 2 < t_end; ++t) {
-        body(buf);
-        if (!(GA_EXP & 2)) issue_tile();                // tile t+2
+        if (NSET == 1 && more2 && !(GA_EXP & 2)) issue_tile(prod);
         if (!(GA_EXP & 4)) __syncthreads();
-        buf ^= 1;
+    };
+    // iteration t: LDS stage (t - t_begin) & 1 holds tile t; with two register sets, set (t + 1 - t_begin) & 1 holds
+    // tile t+1 and tile t+2 is loaded into set (t - t_begin) & 1; with one set, tile t+2 is loaded after the split.
+    int t = t_begin;
+    if (NSET == 1 && t + 1 < t_end) issue_tile(0);      // tile t_begin+1
+    for (; t + 1 < t_end; t += 2) {
+        step(0, NSET == 2 ? 1 : 0, 0, t + 2 < t_end);
+        if (t + 2 >= t_end) break;
+        step(1, 0, NSET == 2 ? 1 : 0, t + 3 < t_end);
     }
-    if (t + 1 < t_end) {
-        body(buf);
-        __syncthreads();
-        buf ^= 1;
-    }
+    const int buf = (t_end - 1 - t_begin) & 1;          // the last tile's stage
     if (t_begin < t_end) mma_tile(buf);
     __syncthreads();        // every wave is done reading the operand tiles before the epilogue reuses the LDS
     GA_STAMP(3)
@@ -315,13 +313,15 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
 template <int WM, int WN, int TM, int TN, int AFF, int ACT, bool DUAL>
 static void launch_bf3_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                             int Ktot, int nkc, int vec_out) {
+    const fastdiv fd_howo = make_fastdiv(d.Ho * d.Wo), fd_wo = make_fastdiv(d.Wo);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out,
+                       fd_howo, fd_wo);
 }
 
 // (dual << 8) | (affine kind << 4) | activation — the key of the instantiated prologue variants

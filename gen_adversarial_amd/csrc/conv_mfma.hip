@@ -34,7 +34,7 @@ constexpr int LDK = 36;
 template <int WM, int WN, int TM, int TN, bool VEC, int PRO, bool FAST>
 __global__ void __launch_bounds__(256)
 conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int Ctot, const int Ktot, const int nkc,
-                 const int vec_out) {
+                 const int vec_out, const fastdiv fd_howo, const fastdiv fd_wo) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int LDC = BN + 4;
@@ -63,7 +63,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + r0 + 32 * i;
         if (m < M) {
-            const int n = m / HoWo, rem = m - n * HoWo, ho = rem / d.Wo, wo = rem - ho * d.Wo;
+            const int n = fd_div(m, fd_howo), rem = m - n * HoWo, ho = fd_div(rem, fd_wo), wo = rem - ho * d.Wo;
             a_n[i] = n; a_h0[i] = ho * d.sn - d.pad; a_w0[i] = wo * d.sn - d.pad;
         } else { a_n[i] = -1; a_h0[i] = 0; a_w0[i] = 0; }
     }
@@ -82,15 +82,7 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
             const int pixb = (a_n[i] * d.Hi + a_h0[i]) * d.Wi + a_w0[i];
             baseA[i] = pixb * d.ldx * 4 + c4 * 16;
             baseA2[i] = pixb * d.ldx2 * 4 + c4 * 16;
-            unsigned mk = 0;
-            if (a_n[i] >= 0) {
-                for (int kh = 0; kh < d.KH; ++kh)
-                    for (int kw = 0; kw < d.KW; ++kw) {
-                        const int hi = a_h0[i] + kh, wi = a_w0[i] + kw;
-                        if (hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) mk |= 1u << (kh * d.KW + kw);
-                    }
-            }
-            maskA[i] = mk;
+            maskA[i] = a_n[i] >= 0 ? tap_mask(a_h0[i], a_w0[i], d.Hi, d.Wi, d.KH, d.KW) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -393,7 +385,8 @@ static void launch_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, si
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out);
+    hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out,
+                       make_fastdiv(d.Ho * d.Wo), make_fastdiv(d.Wo));
 }
 
 template <int WM, int WN, int TM, int TN>

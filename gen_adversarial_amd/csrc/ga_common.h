@@ -54,6 +54,28 @@ __device__ __forceinline__ float act_bwd_fast(float u, int act) {
     }
 }
 
+// ---- division of row indices by image sizes in the conv kernels' setup: n / d for 0 <= n < 2^31 as one 32x32->64 multiply
+//      and a shift (m = ceil(2^(31+s) / d), s = ceil(log2 d): exact because the rounding excess e < d <= 2^s gives
+//      n * e < 2^(31+s)).  The host makes the constants, the kernels take them as arguments.
+struct fastdiv { unsigned m; int s; };
+inline fastdiv make_fastdiv(int d) {
+    int s = 0;
+    while ((1LL << s) < d) ++s;
+    const unsigned long long p = 1ULL << (31 + s);
+    return fastdiv{(unsigned)((p + (unsigned long long)d - 1) / (unsigned long long)d), 31 + s};
+}
+__device__ __forceinline__ int fd_div(int n, const fastdiv f) { return (int)(((unsigned long long)(unsigned)n * f.m) >> f.s); }
+
+// bit (kh*KW + kw) set when tap (kh, kw) of the window whose top-left input pixel is (h0, w0) lies inside the Hi x Wi image
+__device__ __forceinline__ unsigned tap_mask(int h0, int w0, int Hi, int Wi, int KH, int KW) {
+    const int wl = max(0, -w0), wh = min(KW, Wi - w0);
+    const unsigned cols = wh > wl ? ((1u << (wh - wl)) - 1u) << wl : 0u;
+    const int hl = max(0, -h0), hh = min(KH, Hi - h0);
+    unsigned mk = 0;
+    for (int kh = hl; kh < hh; ++kh) mk |= cols << (kh * KW);
+    return mk;
+}
+
 // a sticky error left by an unrelated earlier HIP call must not be blamed on our launch: entry points clear it first
 inline void clear_stale_error() { (void)hipGetLastError(); }
 
