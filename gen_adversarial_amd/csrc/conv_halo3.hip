@@ -1,0 +1,371 @@
+// conv_halo3 — 3x3 / stride 1 / pad 1 convolutions on the split-bf16 matrix path (see conv_bf3.hip for the arithmetic)
+// with the INPUT WINDOW STAGED ONCE PER CHANNEL CHUNK instead of once per tap.
+//
+// The generic implicit-GEMM kernel gathers a fresh [128 pixels][32 channels] operand tile for each of the 9 taps: every
+// input value is fetched from L2, run through the prologue (affine / SiLU / ...) and split into bf16 hi + lo nine
+// times per output-channel tile.  On gfx950 that loader — not the MFMAs — bounds the 3x3 layers (SiLU costs two
+// quarter-rate transcendentals per element).  Here a workgroup owns 128 output pixels that form whole image rows
+// (128/Wo rows of one image, or 128/(Ho*Wo) whole images), stages their halo window ("patch": (TH+2) x (Wo+2) pixels
+// per image, zero padded, 1.4-2.3x the tile instead of 9x) once per 32-channel chunk — prologue and split included —
+// and feeds the 9 taps from it: the A fragment of tap (kh, kw) is the same ds_read_b128 at a uniform LDS offset
+// (kh*(Wo+2) + kw) rows further.  Only the weight tile changes per tap (pre-split bf16, plain copies, double-buffered).
+// Same tile order, epilogue, split-K (over channel chunks) and operand layouts as conv_bf3.
+#include "ga_common.h"
+#include "conv_epilogue.h"
+
+namespace ga {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+#ifdef GA_TRACE     // see conv_bf3.hip: per-workgroup phase stamps for tools/conv_trace.py
+__device__ unsigned long long ga_trace_buf_halo[8 * 8192];
+#define GA_HSTAMP(i)                                                                                     \
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) ga_trace_buf_halo[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define GA_HSTAMP(i)
+#endif
+
+constexpr int HK = 32;          // channels per chunk
+constexpr int LDH = 40;         // bf16 per LDS row (32 + 8 pad = 80 B, conflict-free 16-B fragment reads)
+constexpr int RPMAX = 9;        // patch float4 slots per thread: ceil(288 * 8 / 256)
+constexpr int HALO_PMAX = 288;  // patch pixels a 128-pixel tile may need (8 images of 4x4: 8 * 6 * 6)
+
+// LDS image of the patch: pixel (img, py, px) of a plane at img*IS + py*RS + px*LDH elements.  RS and IS are padded so
+// that tile row r lands on the bank slot of a linear 80-B pitch (80 r mod 256) although the rows of the window are
+// two pixels longer than the tile's: RS = Wo*80 (mod 256) bytes, IS = TH*Wo*80 (mod 256) — the 16-lane groups of the
+// fragment ds_read_b128 then stay conflict-free across row and image boundaries, as in conv_bf3's linear tile.
+struct halo_geom {
+    int TH, NI, PH, PW, P;      // rows per image in the tile, images per tile, patch rows / cols per image, patch pixels
+    int RS, IS;                 // row / image stride of a patch plane, in bf16 elements
+    fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo;
+};
+
+template <int WM, int WN, int TM, int TN, int AFF, int ACT>
+__global__ void __launch_bounds__(256, 2)
+conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C, const int Ktot, const int nkc,
+                  const int vec_out, const halo_geom g) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    static_assert(BM == 128, "the patch geometry is derived for 128-pixel tiles");
+    constexpr int RB = BN >= 64 ? BN / 64 : 1;
+    constexpr int BSTAGE = 2 * BN * LDH;                    // bf16 elements of one weight stage (hi + lo)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Ph = reinterpret_cast<__bf16*>(smem);           // patch, hi then lo: [P][LDH] each
+    __bf16* Pl = Ph + g.NI * g.IS;
+    __bf16* Bst = Pl + g.NI * g.IS;                         // two weight stages
+
+    GA_HSTAMP(0)
+    int bid;
+    {
+        const int nb = gridDim.x, orig = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = orig & 7, k = orig >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = (bid / tilesN) * BM;
+    const int n0 = (bid % tilesN) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int c4 = tid & 7;                                 // this thread's channel quad of the chunk (all its patch slots)
+    const int k8 = tid & 3, rb0 = tid >> 2;                 // weight staging: 4 k-octets x 64 rows
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    constexpr int INV = 0x7fffffff;
+    const int HoWo = d.Ho * d.Wo;
+    const int n_first = fd_div(m0, g.fd_howo);
+    const int y0 = HoWo > BM ? fd_div(m0 - n_first * HoWo, g.fd_wo) : 0;
+    const int rp = (g.P * 8 + 255) >> 8;                    // patch slots per thread in use (uniform)
+
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcWh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_hi), 0, d.w_bytes / 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcWl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_lo), 0, d.w_bytes / 2, 0x00020000);
+
+    // ---- patch slots: slot s = tid + 256 j -> patch pixel s >> 3, channel quad s & 7 (= c4)
+    int pbase[RPMAX], plds[RPMAX];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int j = 0; j < RPMAX; ++j) {
+        const int pp = (tid + 256 * j) >> 3;
+        int off = INV;
+        plds[j] = -1;
+        if (j < rp && pp < g.P) {
+            const int img = fd_div(pp, g.fd_phpw);
+            const int rem = pp - img * g.PH * g.PW;
+            const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
+            plds[j] = img * g.IS + py * g.RS + px * LDH + 4 * c4;
+            const int n = n_first + img, hi = y0 - 1 + py, wi = px - 1;
+            if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
+                off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
+                okbits |= 1u << j;
+            }
+        }
+        pbase[j] = off;
+    }
+    // ---- A fragment rows: tile row o -> patch pixel of the window's top-left tap
+    int fragA[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int o = wm * TM * 32 + i * 32 + lrow;
+        const int img = fd_div(o, g.fd_thwo);
+        const int rem = o - img * g.TH * d.Wo;
+        const int y = fd_div(rem, g.fd_wo), x = rem - y * d.Wo;
+        fragA[i] = img * g.IS + y * g.RS + x * LDH + 8 * lh;
+    }
+    int baseB[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int row = rb0 + 64 * i;
+        const int co = n0 + row;
+        baseB[i] = (row < BN && co < d.Cout) ? (co * Ktot + 8 * k8) * 2 : INV;
+    }
+
+    floatx4 rpat[RPMAX], rs = {1.f, 1.f, 1.f, 1.f}, rt = {0.f, 0.f, 0.f, 0.f};
+    uintx4 rbh[2][RB], rbl[2][RB];       // two weight staging sets: the loads of step s+2 fly during the whole of step s
+
+    auto issue_patch = [&](const int chunk) __attribute__((always_inline)) {
+        const int soff = chunk * HK * 4;
+#pragma unroll
+        for (int j = 0; j < RPMAX; ++j)
+            if (j < rp) rpat[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, pbase[j], soff, 0));
+        if (AFF == 1) {
+            rs = *reinterpret_cast<const floatx4*>(d.pro_scale + chunk * HK + 4 * c4);
+            rt = *reinterpret_cast<const floatx4*>(d.pro_shift + chunk * HK + 4 * c4);
+        }
+    };
+    auto finish_patch = [&]() __attribute__((always_inline)) {
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < RPMAX; ++j) {
+            if (j < rp) {
+                floatx4 v = rpat[j];
+                if (AFF == 1) v = v * rs + rt;
+                if (ACT == GA_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
+                } else if (ACT == GA_ACT_ELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;
+                } else if (ACT == GA_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (AFF != 0) v = (okbits >> j) & 1u ? v : zero;        // only a shift un-zeroes the padding
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
+                if (plds[j] >= 0) {
+                    *reinterpret_cast<bf16x4*>(Ph + plds[j]) = hi;
+                    *reinterpret_cast<bf16x4*>(Pl + plds[j]) = lo;
+                }
+            }
+        }
+    };
+
+    // weight tiles advance tap-fastest inside a chunk: k offset (tap * C + chunk * 32)
+    int q_tap = 0, q_chunk = 0;
+    auto issue_B = [&](const int set) __attribute__((always_inline)) {
+        const int soffB = (q_tap * C + q_chunk * HK) * 2;
+        if (++q_tap == 9) { q_tap = 0; ++q_chunk; }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            rbh[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWh, baseB[i], soffB, 0);
+            rbl[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcWl, baseB[i], soffB, 0);
+        }
+    };
+    auto finish_B = [&](const int set, const int buf) __attribute__((always_inline)) {
+        __bf16* Bh = Bst + buf * BSTAGE;
+        __bf16* Bl = Bh + BN * LDH;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int row = rb0 + 64 * i;
+            if (BN >= 64 || row < BN) {
+                *reinterpret_cast<uintx4*>(Bh + row * LDH + 8 * k8) = rbh[set][i];
+                *reinterpret_cast<uintx4*>(Bl + row * LDH + 8 * k8) = rbl[set][i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto mma_tap = [&](const int buf, const int tapoff) __attribute__((always_inline)) {
+        const __bf16* Bh = Bst + buf * BSTAGE + (wn * TN * 32 + lrow) * LDH + 8 * lh;
+        const __bf16* Bl = Bh + BN * LDH;
+#pragma unroll
+        for (int ks = 0; ks < HK / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ph + fragA[i] + tapoff + ks * 16);
+                al[i] = *reinterpret_cast<const bf16x8*>(Pl + fragA[i] + tapoff + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(Bh + j * 32 * LDH + ks * 16);
+                bl[j] = *reinterpret_cast<const bf16x8*>(Bl + j * 32 * LDH + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    };
+
+    // split-K over channel chunks
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int cper = (nkc + splits - 1) / splits;
+    const int cb = split * cper, ce = min(nkc, cb + cper);
+    const int nsteps = (ce - cb) * 9;
+
+    GA_HSTAMP(1)
+    if (nsteps > 0) {
+        q_chunk = cb;
+        issue_patch(cb);
+        issue_B(0);
+        if (nsteps > 1) issue_B(1);
+        finish_patch();
+        finish_B(0, 0);
+        if (cb + 1 < ce) issue_patch(cb + 1);
+    }
+    __syncthreads();
+    GA_HSTAMP(2)
+    int tap = 0, tapoff = 0, chunk = cb;
+    // step s: weight stage s & 1 feeds the MFMAs; register set s & 1 (drained into that stage one step ago) takes the
+    // loads of step s+2; set (s+1) & 1, loaded during step s-1, is written to the other stage behind the MFMAs
+    auto step = [&](const int par, const int s) __attribute__((always_inline)) {
+#ifndef GA_EXP
+#define GA_EXP 0        // trace builds only: bit 0 drops the weight LDS writes (and with them the loads), 2 the barrier, 3 the MFMAs
+#endif
+        if (s + 2 < nsteps) issue_B(par);
+        if (!(GA_EXP & 8)) mma_tap(par, tapoff);
+        if (s + 1 < nsteps && !(GA_EXP & 1)) finish_B(par ^ 1, par ^ 1);
+        constexpr int NM = TM * TN * 3 * (HK / 16);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 2 * RB * 2, 0);        // MFMAs first: the weight loads have a full step
+#pragma unroll
+        for (int k = 0; k < 2 * RB; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  // one LDS write ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                  // ... per two trailing MFMAs
+        }
+        ++tap;
+        tapoff += LDH;                                      // next column of the window ...
+        if (tap == 3 || tap == 6) tapoff += g.RS - 3 * LDH;      // ... or the start of its next row
+        if (tap == 9) {
+            tap = 0; tapoff = 0; ++chunk;
+            if (chunk < ce) {
+                __syncthreads();                            // every wave has read the old patch
+                finish_patch();
+                if (chunk + 1 < ce) issue_patch(chunk + 1);
+            }
+        }
+        if (!(GA_EXP & 4)) __syncthreads();
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        step(0, s);
+        if (s + 1 < nsteps) step(1, s + 1);
+    }
+    __syncthreads();
+    GA_HSTAMP(3)
+
+    conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
+    GA_HSTAMP(4)
+}
+
+template <int WM, int WN, int TM, int TN, int AFF, int ACT>
+static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ktot,
+                             int nkc, int vec_out, const halo_geom& g) {
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, Ktot,
+                       nkc, vec_out, g);
+}
+
+static inline int halo_mode(const ga_conv_desc& d) {
+    return ((d.pro_scale ? (d.pro_per_row ? 2 : 1) : 0) << 4) | d.pro_act;
+}
+
+// 1 when the descriptor is a 3x3 / stride 1 / pad 1 single-source convolution whose 128-pixel tiles are whole image rows
+int conv_halo3_supports(const ga_conv_desc& d) {
+    if (d.KH != 3 || d.KW != 3 || d.sn != 1 || d.sd != 1 || d.pad != 1 || d.C2 != 0) return 0;
+    if (d.Ho != d.Hi || d.Wo != d.Wi || d.C1 % HK != 0) return 0;
+    const int HoWo = d.Ho * d.Wo;
+    if (128 % d.Wo != 0 || !(HoWo % 128 == 0 || 128 % HoWo == 0)) return 0;
+    switch (halo_mode(d)) {
+        case 0x00: case 0x01: case 0x02: case 0x03: case 0x10: case 0x11: return 1;
+        default: return 0;
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int M = d.N * d.Ho * d.Wo;
+    const int Ktot = 9 * d.C1;
+    const int nkc = d.C1 / HK;
+    const int HoWo = d.Ho * d.Wo;
+    halo_geom g;
+    g.TH = HoWo >= BM ? BM / d.Wo : d.Ho;
+    g.NI = HoWo >= BM ? 1 : BM / HoWo;
+    g.PH = g.TH + 2;
+    g.PW = d.Wo + 2;
+    g.P = g.NI * g.PH * g.PW;
+    if (g.P > HALO_PMAX) return GA_E_UNSUPPORTED;
+    auto pad_to = [](int bytes, int want_mod256) { return bytes + ((want_mod256 - bytes) % 256 + 256) % 256; };
+    const int rs_bytes = pad_to(g.PW * LDH * 2, (d.Wo * LDH * 2) % 256);
+    const int is_bytes = pad_to(g.PH * rs_bytes, (g.TH * d.Wo * LDH * 2) % 256);
+    g.RS = rs_bytes / 2;
+    g.IS = is_bytes / 2;
+    g.fd_howo = make_fastdiv(HoWo);
+    g.fd_wo = make_fastdiv(d.Wo);
+    g.fd_phpw = make_fastdiv(g.PH * g.PW);
+    g.fd_pw = make_fastdiv(g.PW);
+    g.fd_thwo = make_fastdiv(g.TH * d.Wo);
+    if (splits > nkc) return GA_E_UNSUPPORTED;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
+    size_t lds = ((size_t)2 * g.NI * g.IS + (size_t)2 * 2 * BN * LDH) * 2;
+    if (lds > 160 * 1024) return GA_E_UNSUPPORTED;
+    const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    if (lds_c > lds) lds = lds_c;
+    const dim3 grid(tilesM * tilesN, splits);
+#define GA_HALO(A, C) launch_halo_inst<WM, WN, TM, TN, A, C>(d, stream, grid, lds, tilesN, M, Ktot, nkc, vec_out, g)
+    switch (halo_mode(d)) {
+        case 0x00: GA_HALO(0, GA_ACT_NONE); break;
+        case 0x01: GA_HALO(0, GA_ACT_SILU); break;
+        case 0x02: GA_HALO(0, GA_ACT_ELU); break;
+        case 0x03: GA_HALO(0, GA_ACT_RELU); break;
+        case 0x10: GA_HALO(1, GA_ACT_NONE); break;
+        case 0x11: GA_HALO(1, GA_ACT_SILU); break;
+        default: return GA_E_UNSUPPORTED;
+    }
+#undef GA_HALO
+    return check_launch();
+}
+
+// tile codes 5 (128 x 128) and 6 (128 x 64) of ga_conv_desc.tile; called by ga_conv2d after validation
+int conv_halo3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
+    switch (tile) {
+        case 5: return launch_halo<2, 2, 2, 2>(d, stream, vec_out, splits);
+        case 6: return launch_halo<4, 1, 1, 2>(d, stream, vec_out, splits);
+        default: return GA_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace ga
+
+#ifdef GA_TRACE
+extern "C" int ga_debug_trace_read_halo(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ga::ga_trace_buf_halo), (size_t)n * 8) == hipSuccess ? GA_OK : GA_E_LAUNCH;
+}
+#endif

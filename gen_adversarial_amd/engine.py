@@ -434,20 +434,26 @@ class Engine:
             T = d.KH * d.KW * ((d.C1 + d.C2 + 31) // 32)
             best = None
             modes = (1, 0) if d.w_hi else (0,)
-            for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4)]:
-                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32)}[tile]
+            halo = (5, 6) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
+            for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + (halo if m_ else ())]:
+                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64)}[tile]
                 if bn >= 2 * max(32, d.Cout) and tile != 4:
                     continue
                 blocks = -(-M // bm) * -(-d.Cout // bn)
                 for splits in (1, 2, 4, 8, 16, 32):
                     if splits > 1 and (blocks * splits > 2048 or T < 2 * splits or splits * M * d.Cout > WS_FLOATS):
                         continue
+                    if tile >= 5 and splits > d.C1 // 32:          # the halo kernel splits K over 32-channel chunks
+                        continue
                     t = L.ConvDesc.from_buffer_copy(d)
                     t.tile, t.splits = tile, splits
                     if not use_bf3:
                         t.w_hi, t.w_lo = None, None
                     t.ws, t.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
-                    L.run(t, stream)
+                    try:
+                        L.run(t, stream)
+                    except L.GaError:                               # this kernel does not take the shape
+                        continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(reps):

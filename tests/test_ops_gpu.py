@@ -196,6 +196,55 @@ def test_conv_bf16x3(N, H, Cin, Cout, K, act, tile):
     close(nchw(dx), gx, 2e-4, 'bf16x3 bwd')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,act,affine,tile,splits', [
+    (3, 16, 16, 64, 128, 1, True, 5, 1),      # half an image per tile, BN-affine + SiLU prologue
+    (5, 8, 8, 32, 96, 1, False, 6, 1),        # two images per tile, ragged last tile (5 images), Cout not a tile multiple
+    (9, 4, 4, 64, 64, 0, False, 6, 2),        # eight 4x4 images per tile + tail, split-K over channel chunks
+    (2, 32, 32, 32, 40, 3, False, 5, 1),      # 4 image rows per tile, ReLU
+    (1, 64, 64, 32, 32, 2, False, 6, 1),      # 2 image rows per tile, ELU
+    (2, 8, 16, 96, 128, 1, True, 5, 3),       # non-square image, three K splits
+])
+def test_conv_halo3(N, H, W, Cin, Cout, act, affine, tile, splits):
+    """halo-staged 3x3 kernel (tile codes 5/6) against torch: forward with the prologue variants it instantiates, and as
+    the backward-to-input convolution with the act' epilogue.  Same 2e-4 bar as the other split-bf16 kernel."""
+    x = g(N, Cin, H, W, seed=1)
+    w = g(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
+    b = g(Cout, seed=3)
+    sc = (torch.rand(Cin, generator=torch.Generator().manual_seed(4)) + 0.5) if affine else None
+    sh = g(Cin, seed=5, scale=0.3) if affine else None
+    xr = x.clone().requires_grad_(True)
+    u = xr * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) if affine else xr
+    ref = F.conv2d(ACTS[act](u), w, b, padding=1)
+    y = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+    wf = fwd_w(w)
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    ws = torch.empty(max(1, splits * N * H * W * Cout), device=DEV)
+    kw = dict(bias=b.to(DEV), pro_act=act, w_hi=hi, w_lo=lo, splits=splits)
+    if splits > 1:
+        kw.update(ws=ws, ws_floats=ws.numel())
+    if affine:
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV))
+    xd = nhwc(x)
+    run_conv(xd, wf, y, 3, pad=1, tile=tile, **kw)
+    close(nchw(y), ref, 2e-4, 'halo fwd')
+    # backward-to-input of conv(act(x)): 3x3 over the cotangent with flipped weights, times act'(x)
+    if not affine:
+        cot = g(*ref.shape, seed=6)
+        (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+        wb = bwd_w(w)
+        bh = wb.to(torch.bfloat16)
+        bl = (wb - bh.float()).to(torch.bfloat16)
+        dx = torch.full((N, H, W, Cin), float('nan'), device=DEV)
+        kb = dict(dact_x=xd, dact_act=act, lddact=Cin, w_hi=bh, w_lo=bl)
+        if Cout % 32 == 0:
+            run_conv(nhwc(cot), wb, dx, 3, pad=1, tile=tile, **kb)
+            close(nchw(dx), gx, 2e-4, 'halo bwd')
+        else:       # the halo kernel needs 32-channel chunks: the request is refused, not silently rerouted
+            with pytest.raises(L.GaError):
+                run_conv(nhwc(cot), wb, dx, 3, pad=1, tile=tile, **kb)
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)

@@ -49,12 +49,12 @@ e1.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 L.run(d)
 torch.cuda.synchronize()
-bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32)}[tile]
+bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64)}[tile]
 M = N * H * H
 nwg = min(8192, -(-M // bm) * -(-Cout // bn))
 buf = np.zeros(8 * 8192, dtype=np.uint64)
 lib = C.CDLL(os.environ['GA_OPS_LIB'])
-rc = lib.ga_debug_trace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size))
+rc = (lib.ga_debug_trace_read_halo if tile >= 5 else lib.ga_debug_trace_read)(buf.ctypes.data_as(C.c_void_p), C.c_int(buf.size))
 assert rc == 0, rc
 t = buf.reshape(8192, 8)[:nwg].astype(np.int64)
 t0 = t[:, 0].min()
@@ -65,10 +65,6 @@ print(f'conv N{N} H{H} {Cin}->{Cout} k{K} tile{tile} splits{splits} aff{aff} act
 print(f'grid span (first start -> last end): {(t[:, 4].max() - t0)} clk;  starts spread over {(t[:, 0].max() - t0)} clk')
 for i, nm in enumerate(('setup', 'first tile', 'K loop', 'epilogue')):
     print(f'  {nm:10s} mean {ph[:, i].mean():9.0f}  min {ph[:, i].min():8d}  max {ph[:, i].max():8d} clk')
-hw = t[:, 7]
-cu = (hw >> 8) & 0xf
-se = (hw >> 13) & 0x7
-print('workgroups per (se,cu) of this XCD view:', np.unique(se * 16 + cu, return_counts=True)[1][:16], '...')
 # each XCD has its own counter; workgroup i is dispatched to XCD i % 8 -> starts relative to the XCD's first workgroup
 rel = np.zeros(nwg, dtype=np.int64)
 for xcd in range(8):
