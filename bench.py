@@ -42,7 +42,7 @@ def conv_algorithmic_flops(plan):
     return total
 
 
-def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False):
+def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False, store=None):
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, init_nvae_state_dict
     from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
@@ -54,7 +54,7 @@ def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=Fal
     vsd = init_vgg_state_dict(100, 1, seed + 1)
     eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=rows, rep=rep, alphas=alphas,
                  temperature=0.6, noise_eps=float(y['initial_noise_eps']), device=device, precision=precision,
-                 share_encoder=share_encoder)
+                 share_encoder=share_encoder, store=store)
     return eng, (sd, vsd, vspec, alphas)
 
 
@@ -167,6 +167,7 @@ def main():
                     help='defender rows (images x EoT) one plan run processes; a 512-row chunk holds 67 GB of activations')
     ap.add_argument('--streams', type=int, default=2, help='engines / HIP streams the chunks alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-rows256', action='store_true', help='skip the secondary 256-row single-plan measurement')
     ap.add_argument('--share-encoder', action='store_true',
                     help='run the (deterministic) encoder once per image instead of once per EoT replica; identical '
                          'results when initial_noise_eps == 0.  Off by default: the headline number is the literal path')
@@ -275,7 +276,7 @@ def main():
                        'images_per_s': args.images * world * args.steps / dt,
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
-                         'kernel': 'ga::conv_bf3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
+                         'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
                          'peak_note': ('dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-class product; achieved counts '
                                        'algorithmic (1x) flops' if args.precision == 'bf16x3' else 'fp32 MFMA peak'),
@@ -287,6 +288,27 @@ def main():
                                  'plan) on one stream, right after the timed region'},
             'accuracy_counters': [float(counters[0].item()), float(counters[1].item())],
         }
+        if world == 1 and rows_per_step != 256 and not args.no_rows256:
+            # SURVEY.md §8(d) words configs[1] as R = 256 defender rows (8 images x EoT 32) in ONE plan run: the same
+            # attack step at that size, one engine, one stream, reported beside the headline (never as `value`)
+            try:
+                n8 = 256 // args.eot
+                eng8, _ = build_model(device, 256, args.eot, seed=0, precision=args.precision,
+                                      share_encoder=args.share_encoder, store=eng.store)
+                step8 = AttackStep([eng8], [torch.cuda.Stream(device=device)], labels[:n8].clone(), x[:n8].clone())
+                for _ in range(3):
+                    step8()
+                torch.cuda.synchronize()
+                t8 = time.perf_counter()
+                for _ in range(20):
+                    step8()
+                torch.cuda.synchronize()
+                t8 = (time.perf_counter() - t8) / 20
+                out['config']['rows256_single_plan'] = {'rows_per_s': 256 / t8, 'ms_per_step': t8 * 1e3,
+                                                        'what': f'{n8} images x EoT {args.eot} = 256 rows per step, 1 stream'}
+                del step8, eng8
+            except Exception as ex:
+                out['config']['rows256_single_plan'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
         if not args.no_cpu_baseline and world == 1:
             try:
                 log('cpu baseline (oracle on host cores) ...')

@@ -79,7 +79,7 @@ class SamplerDesc(C.Structure):
 class DmlDesc(C.Structure):
     _fields_ = [('logits', fp), ('ld', i32), ('nmix', i32), ('img_nchw', fp), ('img_nhwc', fp),
                 ('dimg_nhwc', fp), ('dimg_nchw', fp), ('dlogits', fp),
-                ('N', i32), ('H', i32), ('W', i32), ('backward', i32)]
+                ('N', i32), ('H', i32), ('W', i32), ('backward', i32), ('ld_img', i32), ('_reserved', i32)]
 
 
 class MaxpoolDesc(C.Structure):
@@ -89,7 +89,8 @@ class MaxpoolDesc(C.Structure):
 
 class ImageIoDesc(C.Structure):
     _fields_ = [('x_nchw', fp), ('noise_nchw', fp), ('noise_coef', fp), ('y_nhwc', fp), ('dy_nhwc', fp),
-                ('dx_nchw', fp), ('N', i32), ('C', i32), ('H', i32), ('W', i32), ('rep', i32), ('backward', i32)]
+                ('dx_nchw', fp), ('N', i32), ('C', i32), ('H', i32), ('W', i32), ('rep', i32), ('backward', i32),
+                ('ld', i32), ('_reserved', i32)]
 
 
 class AxpbyDesc(C.Structure):

@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, cons
     extern __shared__ float dml_s[];
     const int HW = d.H * d.W;
     const int pitch = d.ld + 1;
+    const int ldi = d.ld_img > 0 ? d.ld_img : 3;
     for (long base = (long)blockIdx.x * DML_ROWS; base < npix; base += (long)gridDim.x * DML_ROWS) {
         const int nrow = (int)min((long)DML_ROWS, npix - base);
         __syncthreads();
@@ -313,14 +314,14 @@ __global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, cons
         const int n = (int)(i / HW), pp = (int)(i % HW);
         if (!d.backward) {
             const float o0 = r * 0.5f + 0.5f, o1 = g * 0.5f + 0.5f, o2 = bl * 0.5f + 0.5f;
-            if (d.img_nhwc) { float* o = d.img_nhwc + i * 3; o[0] = o0; o[1] = o1; o[2] = o2; }
+            if (d.img_nhwc) { float* o = d.img_nhwc + i * ldi; o[0] = o0; o[1] = o1; o[2] = o2; for (int z = 3; z < ldi; ++z) o[z] = 0.f; }
             if (d.img_nchw) {
                 float* o = d.img_nchw + (size_t)n * 3 * HW + pp;
                 o[0] = o0; o[HW] = o1; o[2 * HW] = o2;
             }
         } else {
             float dr = 0.f, dg = 0.f, db = 0.f;
-            if (d.dimg_nhwc) { const float* q = d.dimg_nhwc + i * 3; dr += q[0]; dg += q[1]; db += q[2]; }
+            if (d.dimg_nhwc) { const float* q = d.dimg_nhwc + i * ldi; dr += q[0]; dg += q[1]; db += q[2]; }
             if (d.dimg_nchw) { const float* q = d.dimg_nchw + (size_t)n * 3 * HW + pp; dr += q[0]; dg += q[HW]; db += q[2 * HW]; }
             dr *= 0.5f; dg *= 0.5f; db *= 0.5f;
             const float dbp = (bpre >= -1.f && bpre <= 1.f) ? db : 0.f;
@@ -401,6 +402,7 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const ga_maxpool2_desc d,
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d, const long total) {
     const int HW = d.H * d.W;
+    const int ld = d.ld > 0 ? d.ld : d.C;
     if (!d.backward) {
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
             // i indexes NCHW of the N rows (coalesced reads), writes NHWC
@@ -408,7 +410,9 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
             const int c = (int)(q % d.C); const int n = (int)(q / d.C);
             float v = d.x_nchw[((size_t)(n / d.rep) * d.C + c) * HW + p];
             if (d.noise_nchw) v += d.noise_nchw[i] * d.noise_coef[n];
-            d.y_nhwc[((size_t)n * HW + p) * d.C + c] = fminf(fmaxf(v, 0.f), 1.f);
+            float* o = d.y_nhwc + ((size_t)n * HW + p) * ld;
+            o[c] = fminf(fmaxf(v, 0.f), 1.f);
+            if (c == 0) for (int z = d.C; z < ld; ++z) o[z] = 0.f;      // pad channels of a wider pitch
         }
     } else {
         const long total_img = total / d.rep;
@@ -421,7 +425,7 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
                 const int n = img * d.rep + r;
                 float v = x;
                 if (d.noise_nchw) v += d.noise_nchw[((size_t)n * d.C + c) * HW + p] * d.noise_coef[n];
-                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[((size_t)n * HW + p) * d.C + c];
+                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[((size_t)n * HW + p) * ld + c];
             }
             d.dx_nchw[i] = acc;
         }
@@ -573,7 +577,7 @@ extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
     ga::clear_stale_error();
     if (!d || !d->logits || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->nmix <= 0) return GA_E_BADARG;
     if (d->nmix > DML_MAXMIX) return GA_E_UNSUPPORTED;
-    if (d->ld < d->nmix * 10) return GA_E_BADARG;
+    if (d->ld < d->nmix * 10 || (d->ld_img != 0 && d->ld_img < 3)) return GA_E_BADARG;
     if (!d->backward && !d->img_nchw && !d->img_nhwc) return GA_E_BADARG;
     if (d->backward && (!d->dlogits || (!d->dimg_nhwc && !d->dimg_nchw))) return GA_E_BADARG;
     const long npix = (long)d->N * d->H * d->W;
@@ -603,6 +607,7 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
     if ((d->noise_nchw == nullptr) != (d->noise_coef == nullptr)) return GA_E_BADARG;
     if (!d->backward && !d->y_nhwc) return GA_E_BADARG;
     if (d->backward && (!d->dy_nhwc || !d->dx_nchw)) return GA_E_BADARG;
+    if (d->ld != 0 && d->ld < d->C) return GA_E_BADARG;
     const long total = (long)d->N * d->C * d->H * d->W;
     hipLaunchKernelGGL(image_io_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();

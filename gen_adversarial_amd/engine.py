@@ -25,6 +25,7 @@ from .nvae_spec import DecCellSpec, EncCellSpec, NVAESpec, build_spec
 from .vgg_spec import VggSpec
 
 RES_SCALE = 0.1          # `0.1 * self.residual(x)` — architecture.py:133,183
+IMG_LD = 8                  # channel pitch of the NHWC image tensors (3 channels + zero padding)
 WS_FLOATS = 32 * 1024 * 1024     # split-K workspace shared by every conv of an engine (128 MB)
 TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
 _TUNE_CACHE: Optional[dict] = None
@@ -368,17 +369,19 @@ class Engine:
 
         R0 = self.enc_rows                       # rows entering the network (images when the encoder is shared)
         rep0 = 1 if self.share_encoder else self.rep
-        x0 = Act(self, R0, H, H, 3, 'x0')
+        # the NHWC image is kept at a pitch of IMG_LD = 8 channels (3 real + zero pad): the first convolutions then take
+        # 16-B loads and the split-bf16 matrix path like every other layer instead of a scalar 3-channel gather
+        x0 = Act(self, R0, H, H, IMG_LD, 'x0')
         io = L.ImageIoDesc()
         io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
-        io.N, io.C, io.H, io.W, io.rep, io.backward = R0, 3, H, H, rep0, 0
+        io.N, io.C, io.H, io.W, io.rep, io.backward, io.ld = R0, 3, H, H, rep0, 0, IMG_LD
         self.fwd.add(io, 'image_in')
 
         def bwd_image():
             b = L.ImageIoDesc()
             b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef)
             b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(dx_dst)
-            b.N, b.C, b.H, b.W, b.rep, b.backward = R0, 3, H, H, rep0, 1
+            b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld = R0, 3, H, H, rep0, 1, IMG_LD
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
@@ -482,8 +485,8 @@ class Engine:
         self.purified = self.alloc((R, 3, H, H))                            # NCHW
 
         # ---- stem: normalisation (x-0.5)/0.5 as prologue affine, then weight-normed 3x3 (model.py:106-107)
-        stem = self.devd('stem', lambda: F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'))
-        norm = self.devd('norm05', lambda: {'two': torch.full((3,), 2.0), 'mone': torch.full((3,), -1.0)})
+        stem = self.devd('stem', lambda: F.pad_image_conv(F.fold_wn_conv(nvae_sd, 'preprocessing_block.init_conv'), 3, IMG_LD))
+        norm = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
         two, mone = norm['two'], norm['mone']
         RE = self.enc_rows                        # encoder rows: R, or R/rep when the encoder is shared by the replicas
         erep = self.rep if self.share_encoder else 1
@@ -562,10 +565,10 @@ class Engine:
         logits = Act(self, R, H, H, spec.logits_out, 'mix_logits')
         post_out = x
         self.conv(self.fwd, 'to_logits', x.t, tl['w'], logits.t, bias=tl['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
-        img = Act(self, R, H, H, 3, 'purified_nhwc')
+        img = Act(self, R, H, H, IMG_LD, 'purified_nhwc')
         dm = L.DmlDesc()
         dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
-        dm.N, dm.H, dm.W, dm.backward = R, H, H, 0
+        dm.N, dm.H, dm.W, dm.backward, dm.ld_img = R, H, H, 0, IMG_LD
         self.fwd.add(dm, 'dml_mean')
         self.dpurified = self.alloc((R, 3, H, H))    # optional external gradient on the purified image (NCHW)
         purified_img = img
@@ -574,7 +577,7 @@ class Engine:
             b = L.DmlDesc()
             b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
             b.dimg_nchw = _ptr(self.dpurified)
-            b.N, b.H, b.W, b.backward = R, H, H, 1
+            b.N, b.H, b.W, b.backward, b.ld_img = R, H, H, 1, IMG_LD
             self.bwd.add(b, 'dml_mean^T')
             self.grad_conv('to_logits^T', logits.g, tl['w_bwd'], post_out, K=3, pad=1, dact_x=post_out.t, dact_act=L.GA_ACT_ELU)
         self._bwd_steps.append(bwd_dml)
@@ -684,14 +687,15 @@ class Engine:
         """Vgg.forward on the purified image (abstract_models.py:188 -> :53-62): normalise (0.5,0.5) as prologue affine,
         conv+BN folded, ReLU as the next op's prologue, max-pool on pre-activations."""
         vs, R = self.vspec, self.rows
-        norm = self.devd('norm05', lambda: {'two': torch.full((3,), 2.0), 'mone': torch.full((3,), -1.0)})
+        norm = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
         two, mone = norm['two'], norm['mone']
         cur, first = img, True
         pending_pool = None
         for op in vs.program:
             if op[0] == 'conv':
                 _, i, cin, cout = op
-                wts = self.devd(f'vgg.conv{i}', lambda i=i: F.fold_vgg_conv(vsd, i))
+                wts = self.devd(f'vgg.conv{i}', lambda i=i, first=first: F.pad_image_conv(F.fold_vgg_conv(vsd, i), 3, IMG_LD)
+                                if first else F.fold_vgg_conv(vsd, i))
                 t = Act(self, R, cur.h, cur.w, cout, f'vgg.conv{i}')
                 src = cur
                 if first:

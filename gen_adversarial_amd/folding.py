@@ -120,6 +120,21 @@ def fold_wn_conv(sd: SD, prefix: str, out_slice: slice = None, in_slice: slice =
     return {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(b)}
 
 
+def pad_image_conv(f: dict, cin: int, ld: int) -> dict:
+    """Zero-pads the input-channel axis of a folded image-consuming conv from `cin` to the NHWC image pitch `ld`:
+    'w' [Cout][taps*cin] -> [Cout][taps*ld], 'w_bwd' [cin][taps*Cout] -> [ld][taps*Cout] (zero rows).  The pad channels of
+    the image are zero and meet zero weights, so results are unchanged; the conv just sees a vectorisable tensor."""
+    w, wb = f['w'], f['w_bwd']
+    co, taps = w.shape[0], w.shape[1] // cin
+    wp = torch.zeros(co, taps, ld, dtype=w.dtype)
+    wp[:, :, :cin] = w.view(co, taps, cin)
+    wbp = torch.zeros(ld, wb.shape[1], dtype=wb.dtype)
+    wbp[:cin] = wb
+    out = dict(f)
+    out['w'], out['w_bwd'] = wp.reshape(co, taps * ld).contiguous(), wbp.contiguous()
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # VGG
 # ---------------------------------------------------------------------------------------------------------------

@@ -182,6 +182,9 @@ typedef struct ga_dml_desc {
     float* img_nchw; float* img_nhwc;
     const float* dimg_nhwc; const float* dimg_nchw; float* dlogits;
     int N, H, W; int backward;
+    int ld_img;               /* channel pitch of img_nhwc / dimg_nhwc (0 = 3).  With a pitch > 3 the forward also zeroes the
+                                 pad channels, so that the image can feed a vectorised conv as a ld_img-channel tensor */
+    int _reserved;
 } ga_dml_desc;
 int ga_dml_mean(const ga_dml_desc* d, void* stream);
 
@@ -203,6 +206,8 @@ typedef struct ga_image_io_desc {
     const float* dy_nhwc;     /* bwd in  [N,H,W,C] */
     float* dx_nchw;           /* bwd out [N/rep,C,H,W]: sum over the rep rows of each image */
     int N, C, H, W; int rep; int backward;
+    int ld;                   /* channel pitch of y_nhwc / dy_nhwc (0 = C); the forward zero-fills channels C..ld-1 */
+    int _reserved;
 } ga_image_io_desc;
 int ga_image_io(const ga_image_io_desc* d, void* stream);
 

@@ -42,7 +42,7 @@ for b, e in zip(eng.eps, eps): b.copy_(e.cuda())
 eng.forward()
 eng.dlogits.view_as(eng.logits).copy_(cot.cuda())
 eng.backward(); torch.cuda.synchronize()
-print('purified grad', (eng.acts['purified_nhwc'].g.permute(0,3,1,2).cpu() - purified.grad).abs().max().item(), purified.grad.abs().max().item())
+print('purified grad', (eng.acts['purified_nhwc'].g[..., :3].permute(0,3,1,2).cpu() - purified.grad).abs().max().item(), purified.grad.abs().max().item())
 for k in reversed(list(eng.acts.keys())):
     a = eng.acts[k]
     if k in rec and a._g is not None:
@@ -81,7 +81,7 @@ for k in reversed(list(recv.keys())):
     a = eng.acts[k]; r = recv[k].grad
     ag = a.g.permute(0, 3, 1, 2).cpu().reshape(r.shape)
     print(f'{k:30s} gerr {(ag - r).abs().max().item():.3e} ref max {r.abs().max():.3e}')
-print('x grad err', (eng.acts['purified_nhwc'].g.permute(0,3,1,2).cpu() - x.grad).abs().max().item())
+print('x grad err', (eng.acts['purified_nhwc'].g[..., :3].permute(0,3,1,2).cpu() - x.grad).abs().max().item())
 
 for k in ('vgg.conv0', 'vgg.conv4', 'vgg.conv11'):
     t = eng.acts[k].t.permute(0, 3, 1, 2).cpu()
