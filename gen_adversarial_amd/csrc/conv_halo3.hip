@@ -83,12 +83,14 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
 
     // ---- patch slots: slot s = tid + 256 j -> patch pixel s >> 3, channel quad s & 7 (= c4)
     int pbase[RPMAX], plds[RPMAX];
+    int prow[AFF == 2 ? RPMAX : 1];                         // AFF == 2: offset of the slot's image row in pro_scale / pro_shift
     unsigned okbits = 0;
 #pragma unroll
     for (int j = 0; j < RPMAX; ++j) {
         const int pp = (tid + 256 * j) >> 3;
         int off = INV;
         plds[j] = -1;
+        if (AFF == 2) prow[j] = 0;
         if (j < rp && pp < g.P) {
             const int img = fd_div(pp, g.fd_phpw);
             const int rem = pp - img * g.PH * g.PW;
@@ -98,6 +100,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
                 off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
                 okbits |= 1u << j;
+                if (AFF == 2) prow[j] = n * C + 4 * c4;
             }
         }
         pbase[j] = off;
@@ -133,6 +136,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             rt = *reinterpret_cast<const floatx4*>(d.pro_shift + chunk * HK + 4 * c4);
         }
     };
+    int cur_chunk = 0;                                      // chunk whose data sits in rpat (for the per-row affine)
     auto finish_patch = [&]() __attribute__((always_inline)) {
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -140,6 +144,11 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             if (j < rp) {
                 floatx4 v = rpat[j];
                 if (AFF == 1) v = v * rs + rt;
+                if (AFF == 2) {     // per-(image, channel) scale / shift: small and L2-resident, fetched as the slot is converted
+                    const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow[j] + cur_chunk * HK);
+                    const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow[j] + cur_chunk * HK);
+                    v = v * ps + pt;
+                }
                 if (ACT == GA_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
@@ -232,6 +241,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
         issue_patch(cb);
         issue_B(0);
         if (nsteps > 1) issue_B(1);
+        cur_chunk = cb;
         finish_patch();
         finish_B(0, 0);
         if (cb + 1 < ce) issue_patch(cb + 1);
@@ -262,6 +272,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             tap = 0; tapoff = 0; ++chunk;
             if (chunk < ce) {
                 __syncthreads();                            // every wave has read the old patch
+                cur_chunk = chunk;
                 finish_patch();
                 if (chunk + 1 < ce) issue_patch(chunk + 1);
             }
@@ -303,7 +314,7 @@ int conv_halo3_supports(const ga_conv_desc& d) {
     const int HoWo = d.Ho * d.Wo;
     if (128 % d.Wo != 0 || !(HoWo % 128 == 0 || 128 % HoWo == 0)) return 0;
     switch (halo_mode(d)) {
-        case 0x00: case 0x01: case 0x02: case 0x03: case 0x10: case 0x11: return 1;
+        case 0x00: case 0x01: case 0x02: case 0x03: case 0x10: case 0x11: case 0x20: return 1;
         default: return 0;
     }
 }
@@ -347,6 +358,7 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
         case 0x03: GA_HALO(0, GA_ACT_RELU); break;
         case 0x10: GA_HALO(1, GA_ACT_NONE); break;
         case 0x11: GA_HALO(1, GA_ACT_SILU); break;
+        case 0x20: GA_HALO(2, GA_ACT_NONE); break;
         default: return GA_E_UNSUPPORTED;
     }
 #undef GA_HALO

@@ -245,6 +245,23 @@ def test_conv_halo3(N, H, W, Cin, Cout, act, affine, tile, splits):
                 run_conv(nhwc(cot), wb, dx, 3, pad=1, tile=tile, **kb)
 
 
+def test_conv_halo3_per_row_prologue():
+    """the SE-gate prologue of the encoder cells' conv2^T (per-(row, channel) scale and shift) on the halo kernel"""
+    N, H, Cin, Cout = 5, 8, 64, 96
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
+    sc = torch.rand(N, Cin, generator=torch.Generator().manual_seed(3)) + 0.5
+    sh = g(N, Cin, seed=4, scale=0.3)
+    ref = F.conv2d(x * sc.view(N, Cin, 1, 1) + sh.view(N, Cin, 1, 1), w, None, padding=1)
+    wf = fwd_w(w)
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    for tile in (5, 6):
+        y = torch.full((N, H, H, Cout), float('nan'), device=DEV)
+        run_conv(nhwc(x), wf, y, 3, pad=1, tile=tile, pro_scale=sc.to(DEV), pro_shift=sh.to(DEV), pro_per_row=1, w_hi=hi, w_lo=lo)
+        close(nchw(y), ref, 2e-4, f'halo per-row prologue tile {tile}')
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)

@@ -19,14 +19,15 @@ tile = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 splits = int(sys.argv[7]) if len(sys.argv) > 7 else 1
 aff = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 act = int(sys.argv[9]) if len(sys.argv) > 9 else 0
+odd_ld = int(sys.argv[10]) if len(sys.argv) > 10 else 0      # 1: output pitch Cout+1 -> scalar (direct-from-accumulator) epilogue
 x = torch.randn(N, H, H, Cin, device='cuda')
 w = torch.randn(Cout, K * K * Cin, device='cuda') * 0.05
-y = torch.empty(N, H, H, Cout, device='cuda')
+y = torch.empty(N, H, H, Cout + (1 if len(sys.argv) > 10 and int(sys.argv[10]) else 0), device='cuda')
 ws = torch.empty(max(1, splits * N * H * H * Cout), device='cuda')
 sc = torch.rand(Cin, device='cuda') + 0.5
 sh = torch.randn(Cin, device='cuda') * 0.1
 d = L.ConvDesc()
-d.x, d.ldx, d.C1, d.w, d.y, d.ldy, d.Cout = x.data_ptr(), Cin, Cin, w.data_ptr(), y.data_ptr(), Cout, Cout
+d.x, d.ldx, d.C1, d.w, d.y, d.ldy, d.Cout = x.data_ptr(), Cin, Cin, w.data_ptr(), y.data_ptr(), y.shape[3], Cout
 d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad, d.tile, d.pro_act = N, H, H, H, H, K, K, 1, 1, K // 2, tile, act
 d.splits = splits
 if splits > 1:
