@@ -173,7 +173,7 @@ extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
     const int halo_bytes = (TH + 4) * (TW + 4) * DW_CC * 4;
     int NB = 256 / (TH * TW);
     if (NB < 1) NB = 1;
-    const int fit = (36 * 1024 - 25 * DW_CC * 4) / halo_bytes;
+    const int fit = (40 * 1024 - 25 * DW_CC * 4) / halo_bytes;        // 4 workgroups x 40 KB = the CU's 160 KB
     if (NB > fit) NB = fit;
     if (NB > d.N) NB = d.N;
     if (NB < 1) NB = 1;
@@ -184,8 +184,9 @@ extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
     const size_t lds = (size_t)NB * halo_bytes + 25 * DW_CC * 4;
     // strips of 4 when every tile width is a multiple of 4 (the strip reads SW+4 columns: stays inside the halo),
     // else strips of 2 (pool2 needs an even strip), else single outputs
-    const bool w4 = (d.W % 4 == 0) && (TW % 4 == 0);
+    // (small images: strips of 2 when strips of 4 would leave half of the 32 strip lanes without work)
     const bool w2 = (d.W % 2 == 0) && (TW % 2 == 0);
+    const bool w4 = (d.W % 4 == 0) && (TW % 4 == 0) && !(w2 && NB * TH * (TW / 4) < 32);
     if (w4) hipLaunchKernelGGL(dwconv5_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, stream, d, NB, TH, TW, tilesH, tilesW, nchunks);
     else if (w2) hipLaunchKernelGGL(dwconv5_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, stream, d, NB, TH, TW, tilesH, tilesW, nchunks);
     else {
