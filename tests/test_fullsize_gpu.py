@@ -1,0 +1,188 @@
+"""
+GPU tests at the FULL size of BASELINE.json configs[1]: the assumed NVAE configuration (C=32, 3 scales x 8 groups,
+20 latents, 64x64), the full-width VGG-11 (25088-wide projector head), EoT 32, alphas of
+configs/ours_cosine_no_preprocessing_ids.yaml x 0.7 — the engine bench.py measures.
+
+  * direct parity with the CPU oracle on 4 rows (2 images x EoT 2): the oracle needs ~1 s per row at this size;
+  * size-independent properties on 64 rows (2 images x EoT 32): linearity of the backward pass in its cotangent,
+    replica invariance (equal latent noise => bitwise equal rows), exactness of the shared-encoder de-duplication,
+    row independence (a 64-row plan equals two 32-row plans), and a directional-derivative check of the NVAE gradient.
+Tolerance 1e-3 absolute as BASELINE.json's north_star states; observed ~2e-5.
+"""
+import os
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd.engine import Engine, WeightStore   # noqa: E402
+from gen_adversarial_amd.nvae_spec import (ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, build_spec,   # noqa: E402
+                                           init_nvae_state_dict)
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   # noqa: E402
+
+DEV = 'cuda:0'
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def model():
+    with open(os.path.join(ROOT, 'configs', 'ours_cosine_no_preprocessing_ids.yaml')) as f:
+        y = yaml.safe_load(f)
+    alphas = [a * y['alpha_attenuation'] for a in y['interpolation_alphas']]
+    sd = init_nvae_state_dict(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, 0)
+    vspec = build_vgg_spec(100, 1)
+    vsd = init_vgg_state_dict(100, 1, 1)
+    return {'sd': sd, 'vsd': vsd, 'vspec': vspec, 'alphas': alphas, 'store': WeightStore(DEV),
+            'spec': build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION)}
+
+
+def engine(m, rows, rep, **kw):
+    return Engine(m['sd'], ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, m['vsd'], m['vspec'], rows=rows, rep=rep,
+                  alphas=m['alphas'], temperature=0.6, noise_eps=0.0, device=DEV, store=m['store'], **kw)
+
+
+def fill(eng, imgs, eps):
+    eng.x_in.copy_(imgs.to(DEV))
+    for b, e in zip(eng.eps, eps):
+        b.copy_(e.to(DEV))
+
+
+def err(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def rel_l2(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).norm() / b.norm()).item()
+
+
+def test_fullsize_parity_with_the_oracle(model):
+    from oracle import defender_oracle as D
+    from oracle import nvae_oracle as O
+    m, spec = model, model['spec']
+    rows, rep = 4, 2
+    gen = torch.Generator().manual_seed(11)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    xr = imgs.clone().requires_grad_(True)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    purified = O.nvae_purify(m['sd'], spec, xr.repeat_interleave(rep, dim=0), m['alphas'], eps, 0.6)
+    cot_img = torch.randn(purified.shape, generator=gen)
+    (gx_img,) = torch.autograd.grad((purified * cot_img).sum(), [xr], retain_graph=True)
+    logits = D.classifier_call(m['vsd'], m['vspec'], purified)
+    cot = torch.randn(logits.shape, generator=gen)
+    (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
+
+    eng = engine(m, rows, rep)
+    fill(eng, imgs, eps)
+    eng.forward()
+    e_p, e_l = err(eng.purified, purified), err(eng.logits, logits)
+    eng.dpurified.copy_(cot_img.to(DEV))
+    eng.backward(from_logits=False, from_purified=True)
+    e_gi, gi_max = err(eng.dx, gx_img), gx_img.abs().max().item()
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    diff = (eng.dx.cpu() - gx).double()
+    rel_l2 = (diff.norm() / gx.double().norm()).item()
+    print(f'full-size oracle parity: purified {e_p:.2e} logits {e_l:.2e} (|logits| {logits.abs().max().item():.2f}) '
+          f'nvae-grad {e_gi:.2e} (max {gi_max:.2e}) full-grad relL2 {rel_l2:.2e}')
+    assert e_p < TOL and e_l < TOL
+    assert e_gi < TOL * max(1.0, gi_max)
+    assert rel_l2 < 2e-2                      # max-pool near-ties (see test_engine_gpu.py)
+
+
+def test_fullsize_properties(model):
+    m, spec = model, model['spec']
+    rows, rep = 64, 32
+    gen = torch.Generator().manual_seed(12)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    eng = engine(m, rows, rep)
+    fill(eng, imgs, eps)
+    eng.forward()
+    logits = eng.logits.clone()
+    purified = eng.purified.clone()
+    assert torch.isfinite(logits).all() and 0.0 <= purified.min().item() and purified.max().item() <= 1.0
+
+    # ---- the backward pass is linear in its cotangent
+    a = torch.randn(logits.shape, generator=gen).to(DEV)
+    b = torch.randn(logits.shape, generator=gen).to(DEV)
+    grads = []
+    for c in (a, b, a + b):
+        eng.dlogits.view_as(eng.logits).copy_(c)
+        eng.backward()
+        grads.append(eng.dx.clone())
+    lin = err(grads[2], grads[0] + grads[1])
+    scale = grads[2].abs().max().item()
+    print(f'backward linearity: {lin:.2e} of {scale:.2e}')
+    assert lin < 1e-4 * max(1.0, scale)
+    # gradient through the purifier alone (cotangent on the purified image): smooth, compared strictly below; the
+    # classifier's max-pools make the full gradient discontinuous at near-ties, so that one is compared in relative L2
+    u64 = torch.randn(purified.shape, generator=gen).to(DEV)
+    eng.dpurified.copy_(u64)
+    eng.backward(from_logits=False, from_purified=True)
+    g_nvae = eng.dx.clone()
+    s_nvae = g_nvae.abs().max().item()
+
+    # ---- row independence: the same rows through two 32-row plans
+    half = engine(m, 32, 32)
+    for i in range(2):
+        fill(half, imgs[i:i + 1], [e[32 * i:32 * (i + 1)] for e in eps])
+        half.forward()
+        assert err(half.logits, logits[32 * i:32 * (i + 1)]) < 1e-4
+        half.dlogits.view_as(half.logits).copy_(a[32 * i:32 * (i + 1)])
+        half.backward()
+        assert rel_l2(half.dx, grads[0][i:i + 1]) < 2e-2
+        half.dpurified.copy_(u64[32 * i:32 * (i + 1)])
+        half.backward(from_logits=False, from_purified=True)
+        assert err(half.dx, g_nvae[i:i + 1]) < 1e-4 * max(1.0, s_nvae)
+
+    # ---- EoT replicas with equal latent noise are the same computation: bitwise equal rows
+    same = [e[::rep].repeat_interleave(rep, dim=0) for e in eps]
+    fill(eng, imgs, same)
+    eng.forward()
+    lg = eng.logits.view(rows // rep, rep, -1)
+    assert torch.equal(lg, lg[:, :1].expand_as(lg))
+
+    # ---- the shared encoder (one encoder pass per image) is exact when no input noise is configured
+    shared = engine(m, rows, rep, share_encoder=True)
+    assert shared.share_encoder and shared.enc_rows == rows // rep
+    fill(shared, imgs, eps)
+    shared.forward()
+    assert err(shared.logits, logits) < 1e-4 and err(shared.purified, purified) < 1e-5
+    shared.dlogits.view_as(shared.logits).copy_(a)
+    shared.backward()
+    assert rel_l2(shared.dx, grads[0]) < 2e-2
+    shared.dpurified.copy_(u64)
+    shared.backward(from_logits=False, from_purified=True)
+    assert err(shared.dx, g_nvae) < 1e-4 * max(1.0, s_nvae)
+
+    # ---- directional derivative of the purifier (smooth leg, exact-fp32 kernels) against central differences, with the
+    # cotangent aligned to the response so that the inner product is well conditioned: <D, J v> = |D|^2 for D = J v
+    fp = engine(m, 2, 1, precision='fp32')
+    x0 = imgs.clamp(0.05, 0.95)
+    e1 = [e[::rep].contiguous() for e in eps]
+    v = torch.randn(x0.shape, generator=gen)
+    v = v / v.flatten(1).norm(dim=1).view(-1, 1, 1, 1)
+    h = 2e-2
+    outs = []
+    for sgn in (+1.0, -1.0):
+        fill(fp, x0 + sgn * h * v, e1)
+        fp.forward()
+        outs.append(fp.purified.clone())
+    D = (outs[0] - outs[1]) / (2 * h)
+    numeric = (D * D).flatten(1).sum(dim=1).cpu()
+    fill(fp, x0, e1)
+    fp.forward()
+    fp.dpurified.copy_(D)
+    fp.backward(from_logits=False, from_purified=True)
+    analytic = (fp.dx.cpu() * v).flatten(1).sum(dim=1)
+    rel = ((analytic - numeric).abs() / numeric.abs()).max().item()
+    print(f'directional derivative: analytic {analytic.tolist()} numeric {numeric.tolist()} rel {rel:.2e}')
+    assert rel < 3e-2
