@@ -433,6 +433,35 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// sub-pixel assembly of a stride-2 transposed conv: y[n, 2i+a, 2j+b, :] = epilogue(s[a][b][n, i, j, :])
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) interleave2_kernel(const ga_interleave2_desc d, const long total4) {
+    const int C4 = d.C / 4, Hh = d.H / 2, Wh = d.W / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4); long p = i / C4;               // p = output pixel (n, h, w)
+        const int w = (int)(p % d.W); long r = p / d.W;
+        const int h = (int)(r % d.H); const long n = r / d.H;
+        const float* src = d.s[h & 1][w & 1];
+        floatx4 v = {0.f, 0.f, 0.f, 0.f};
+        if (src) v = *reinterpret_cast<const floatx4*>(src + (((size_t)n * Hh + (h >> 1)) * Wh + (w >> 1)) * d.C + 4 * q);
+        const size_t o = (size_t)p * d.C + 4 * q;
+        if (d.dact_x) {
+            floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
+            floatx4 ds = {1.f, 1.f, 1.f, 1.f};
+            if (d.dact_scale) {
+                ds = *reinterpret_cast<const floatx4*>(d.dact_scale + 4 * q);
+                u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + 4 * q);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+        }
+        if (d.addend) v += *reinterpret_cast<const floatx4*>(d.addend + o);
+        if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + o);
+        *reinterpret_cast<floatx4*>(d.y + o) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // separable Gaussian blur, reflect border (kornia gaussian_blur2d semantics), one image plane per workgroup in LDS
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect_idx(int t, const int n) {       // 'reflect' (no edge repeat): -1 -> 1, n -> n-2
@@ -620,6 +649,16 @@ extern "C" int ga_gauss_blur(const ga_blur_desc* d, void* s) {
     const size_t lds = ((size_t)2 * d->H * d->W + d->k) * sizeof(float);
     if (lds > 64 * 1024) return GA_E_UNSUPPORTED;            // planes up to ~90 x 90; larger images are a next row
     hipLaunchKernelGGL(gauss_blur_kernel, dim3(d->planes), dim3(256), lds, (hipStream_t)s, *d);
+    return check_launch();
+}
+
+extern "C" int ga_interleave2(const ga_interleave2_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->y || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (((d->H | d->W) & 1) || (d->C % 4)) return GA_E_UNSUPPORTED;
+    if ((d->dact_scale == nullptr) != (d->dact_shift == nullptr)) return GA_E_BADARG;
+    const long total4 = (long)d->N * d->H * d->W * (d->C / 4);
+    hipLaunchKernelGGL(interleave2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }
 

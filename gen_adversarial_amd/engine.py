@@ -45,7 +45,8 @@ def tune_cache() -> dict:
 def conv_key(d) -> str:
     return ('b3_' if d.w_hi else '') + '_'.join(str(int(v)) for v in (
         d.N * d.Ho * d.Wo, d.Cout, d.C1, d.C2, d.KH, d.sn, d.sd, d.Hi, d.pro_act, bool(d.pro_scale), d.pro_per_row,
-        bool(d.dact_x), d.dact_act, bool(d.addend), bool(d.addend2), d.addend_bcast_n))
+        bool(d.dact_x), d.dact_act, bool(d.addend), bool(d.addend2), d.addend_bcast_n)) + (
+        f'_kw{d.KW}' if d.KW != d.KH else '')
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -162,7 +163,7 @@ class Engine:
     def conv(self, plan, name, x, w, y, *, cin=None, cout=None, bias=None, K=1, sn=1, sd=1, pad=0,
              x2=None, pro_scale=None, pro_shift=None, pro_act=0, pro_per_row=0,
              addend=None, addend_bcast=False, addend2=None, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0,
-             in_hw=None, out_hw=None, n=None):
+             in_hw=None, out_hw=None, n=None, KH=None, KW=None, anchored=False):
         """x, x2, y, addend*, dact_x are torch tensors [N,H,W,C] (or Act.t); shapes are taken from them."""
         d = L.ConvDesc()
         N, Hi, Wi, Cx = x.shape
@@ -186,11 +187,13 @@ class Engine:
             d.dact_x, d.lddact = _ptr(dact_x), dact_x.shape[-1]
             d.dact_scale, d.dact_shift, d.dact_act = _ptr(dact_scale), _ptr(dact_shift), dact_act
         d.N, d.Hi, d.Wi, d.Ho, d.Wo = N, Hi, Wi, Ho, Wo
-        d.KH = d.KW = K
+        d.KH, d.KW = (KH or K), (KW or K)
         d.sn, d.sd, d.pad = sn, sd, pad
         assert No == N, (name, x.shape, y.shape)
-        assert w.numel() == d.Cout * K * K * (d.C1 + d.C2), (name, tuple(w.shape), d.Cout, K, d.C1, d.C2)
-        if sd == 1:
+        assert w.numel() == d.Cout * d.KH * d.KW * (d.C1 + d.C2), (name, tuple(w.shape), d.Cout, d.KH, d.KW, d.C1, d.C2)
+        if anchored:            # sub-pixel kernels: window anchored at the output pixel, taps beyond the border masked
+            assert (Ho, Wo) == (Hi, Wi) and pad == 0 and sn == 1 and sd == 1, name
+        elif sd == 1:
             assert (Hi + 2 * pad - K) // sn + 1 == Ho, (name, Hi, Ho, K, sn, pad)
         else:
             assert Ho in (Hi * sd, Hi * sd - 1) or K == 1, (name, Hi, Ho)
@@ -206,6 +209,29 @@ class Engine:
             else:
                 addend2 = target.g
         self.conv(self.bwd, name, x, w, target.g, addend=addend, addend2=addend2, **kw)
+        target.g_written = True
+
+    def grad_conv_up2(self, name, x, wts, key, target: Act, *, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0):
+        """Backward-to-input of a stride-2 conv into target.g (twice the resolution of x) by sub-pixel decomposition:
+        one stride-1 ga_conv2d per output parity that meets a tap (folding.subpixel_weights) into dense scratch planes,
+        then ga_interleave2, which carries the epilogue (act', accumulation into an already written gradient)."""
+        n, h, w, _ = x.shape
+        il = L.Interleave2Desc()
+        for a in (0, 1):
+            for b in (0, 1):
+                wm = wts.get(f'{key}{a}{b}')
+                if wm is None:
+                    continue
+                taps = wm.shape[1] // x.shape[3]                    # 1, 2 or 4 taps: 1x1, 2x1 / 1x2, 2x2 windows
+                kh, kw = 1 + (a if taps >= 2 else 0), 1 + (b if taps >= 2 else 0)
+                plane = self.scratch((n, h, w, target.c), f'subpix{a}{b}')
+                self.conv(self.bwd, f'{name}[{a}{b}]', x, wm, plane, KH=kh, KW=kw, pad=0, anchored=True)
+                il.s[2 * a + b] = _ptr(plane)
+        il.y, il.N, il.H, il.W, il.C = _ptr(target.g), n, 2 * h, 2 * w, target.c
+        il.dact_x, il.dact_scale, il.dact_shift, il.dact_act = _ptr(dact_x), _ptr(dact_scale), _ptr(dact_shift), dact_act
+        if target.g_written:
+            il.addend = _ptr(target.g)
+        self.bwd.add(il, name + '.interleave')
         target.g_written = True
 
     def se_forward(self, name, t: Act, wts, P):
@@ -272,12 +298,13 @@ class Engine:
             dt1 = self.scratch((n, ho, wo, cell.cout), 'enc_dt1')
             self.conv(self.bwd, p + '.conv2^T', out.g, wts['w2_bwd'], dt1, K=3, pad=1,
                       pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t1.t, dact_act=L.GA_ACT_SILU)
-            self.grad_conv(p + '.conv1^T', dt1, wts['w1_bwd'], x, K=3, sn=1, sd=st, pad=1,
-                           primary=None if cell.down else out.g,
-                           dact_x=x.t, dact_scale=wts['pro_scale'], dact_shift=wts['pro_shift'], dact_act=L.GA_ACT_SILU)
-            if cell.down:
-                self.grad_conv(p + '.skip^T', out.g, wts['ws_bwd'], x, K=1, sn=1, sd=2, pad=0,
-                               dact_x=x.t, dact_act=L.GA_ACT_SILU)
+            if cell.down:       # both stride-2 transposes by sub-pixel decomposition (stride-1 convs on the matrix path)
+                self.grad_conv_up2(p + '.conv1^T', dt1, wts, 'w1_sub', x, dact_x=x.t, dact_scale=wts['pro_scale'],
+                                   dact_shift=wts['pro_shift'], dact_act=L.GA_ACT_SILU)
+                self.grad_conv_up2(p + '.skip^T', out.g, wts, 'ws_sub', x, dact_x=x.t, dact_act=L.GA_ACT_SILU)
+            else:
+                self.grad_conv(p + '.conv1^T', dt1, wts['w1_bwd'], x, K=3, sn=1, sd=1, pad=1, primary=out.g,
+                               dact_x=x.t, dact_scale=wts['pro_scale'], dact_shift=wts['pro_shift'], dact_act=L.GA_ACT_SILU)
         self._bwd_steps.append(backward)
         return out
 

@@ -54,6 +54,33 @@ def dw_layout(w: torch.Tensor, flip: bool = False) -> torch.Tensor:
     return w.reshape(w.shape[0], 25).t().contiguous()
 
 
+def subpixel_weights(w: torch.Tensor) -> dict:
+    """Backward-to-input of a stride-2 convolution (pad = (k-1)//2, k in {1, 3}) as four stride-1 convolutions, one per
+    output parity (a, b) = (row, column parity of the input pixel): hi = 2*ho + kh - pad, so parity a only meets the
+    taps kh with (a + pad - kh) even, at ho = i + (a + pad - kh)/2 for hi = 2i + a.  Each sub-kernel is returned in the
+    forward layout of ga_conv2d — [Cin][th*KW_ab*Cout + tw*Cout + co], taps ordered by increasing offset, window
+    anchored at (i, j), pad 0 — together with its (KH_ab, KW_ab); a parity that meets no tap is absent (its plane is
+    zero).  w: [Cout, Cin, k, k] (the folded forward weights)."""
+    co, ci, k, _ = w.shape
+    pad = (k - 1) // 2
+
+    def taps(a):      # [(offset, kh)] sorted by offset
+        t = [((a + pad - kh) // 2, kh) for kh in range(k) if (a + pad - kh) % 2 == 0]
+        t.sort()
+        assert [o for o, _ in t] == list(range(len(t))), (k, a, t)          # offsets 0.. : a plain window with pad 0
+        return [kh for _, kh in t]
+
+    out = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            ta, tb = taps(a), taps(b)
+            if not ta or not tb:
+                continue
+            sub = w[:, :, ta][:, :, :, tb]                                    # [co, ci, KHab, KWab]
+            out[(a, b)] = (f32(sub.permute(1, 2, 3, 0).reshape(ci, -1)), len(ta), len(tb))
+    return out
+
+
 def f32(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 
@@ -77,6 +104,9 @@ def fold_enc_cell(sd: SD, cell) -> dict:
         out['ws'] = f32(conv_fwd_layout(ws))
         out['ws_bwd'] = f32(conv_bwd_layout(ws))
         out['bs'] = f32(sd[f'{p}.skip_connection.conv.bias'].double())
+        for key, wsrc in (('w1_sub', w1f), ('ws_sub', ws)):                  # sub-pixel kernels of the two stride-2 transposes
+            for (a, b), (wm, kh, kw) in subpixel_weights(wsrc).items():
+                out[f'{key}{a}{b}'] = wm
     return out
 
 

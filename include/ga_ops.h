@@ -230,6 +230,25 @@ int ga_split_bf16(const float* w, void* hi, void* lo, long n, void* stream);
  * gradient of a tensor shared by `rep` EoT replicas */
 int ga_rep_sum(const float* x, float* y, long rows, long inner, int rep, int accumulate, void* stream);
 
+/* Sub-pixel assembly of a stride-2 transposed convolution (the backward-to-input of a stride-2 conv, e.g.
+ * ResidualCellEncoder's down-sampling conv and SkipDown, architecture.py:64-82,119-122).  The transposed conv splits
+ * into four stride-1 convolutions, one per output parity (a, b): output pixel (2i+a, 2j+b) only sees the taps whose
+ * parity matches, so each runs as an ordinary ga_conv2d over the half-resolution cotangent with a 1x1 / 1x2 / 2x1 / 2x2
+ * kernel (weights: folding.subpixel_weights).  This op interleaves their dense results s[a][b] = [N, H/2, W/2, C] into
+ * y = [N, H, W, C] and applies the conv epilogue on the way:
+ *   y[n, 2i+a, 2j+b, c] = s[a][b][n, i, j, c] * act'(dact_x*dact_scale + dact_shift)*dact_scale + addend + addend2
+ * A NULL s[a][b] is a zero plane (a 1x1 stride-2 conv only feeds parity (0, 0)).  addend may alias y. */
+typedef struct ga_interleave2_desc {
+    const float* s[2][2];
+    float* y;
+    const float* dact_x; const float* dact_scale; const float* dact_shift;   /* [N,H,W,C], [C], [C] or NULL */
+    const float* addend; const float* addend2;                              /* [N,H,W,C] or NULL */
+    int N, H, W, C;           /* output size; H, W even, C % 4 == 0 */
+    int dact_act;             /* ga_act */
+    int _reserved;
+} ga_interleave2_desc;
+int ga_interleave2(const ga_interleave2_desc* d, void* stream);
+
 /* y = alpha*x + beta*y over n floats */
 int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* stream);
 
@@ -238,7 +257,7 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
  * ------------------------------------------------------------------------------------------------------------------ */
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
-                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13 };
+                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -247,7 +266,7 @@ typedef struct ga_op {
     union {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
-        ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs;
+        ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -262,6 +262,47 @@ def test_conv_halo3_per_row_prologue():
         close(nchw(y), ref, 2e-4, f'halo per-row prologue tile {tile}')
 
 
+@pytest.mark.parametrize('k,bf3', [(3, True), (3, False), (1, True)])
+def test_stride2_transpose_by_subpixel_convs(k, bf3):
+    """backward-to-input of a stride-2 conv as four anchored stride-1 ga_conv2d launches + ga_interleave2 (with act' and
+    accumulation), against autograd"""
+    from gen_adversarial_amd.folding import subpixel_weights
+    N, Cin, Cout, h = 3, 32, 64, 8
+    x = g(N, Cin, 2 * h, 2 * h, seed=1)
+    w = g(Cout, Cin, k, k, seed=2, scale=1.0 / np.sqrt(Cin * k * k))
+    xr = x.clone().requires_grad_(True)
+    y = F.conv2d(F.silu(xr), w, stride=2, padding=(k - 1) // 2)
+    cot = g(*y.shape, seed=3)
+    (gx,) = torch.autograd.grad((y * cot).sum(), [xr])
+    prev = g(N, Cin, 2 * h, 2 * h, seed=4)                       # a gradient already accumulated in the target
+    dy = nhwc(cot)
+    il = L.Interleave2Desc()
+    keep = []
+    for (a, b), (wm, kh, kw) in subpixel_weights(w.double()).items():
+        wd = wm.to(DEV)
+        plane = torch.full((N, h, h, Cin), float('nan'), device=DEV)
+        kwargs = {}
+        if bf3:
+            hi = wd.to(torch.bfloat16)
+            kwargs = dict(w_hi=hi, w_lo=(wd - hi.float()).to(torch.bfloat16))
+        d = L.ConvDesc()
+        d.x, d.ldx, d.C1, d.w, d.y, d.ldy, d.Cout = dy.data_ptr(), Cout, Cout, wd.data_ptr(), plane.data_ptr(), Cin, Cin
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad = N, h, h, h, h, kh, kw, 1, 1, 0
+        for kk, v in kwargs.items():
+            keep.append(v)
+            setattr(d, kk, v.data_ptr())
+        L.run(d)
+        il.s[2 * a + b] = plane.data_ptr()
+        keep += [wd, plane]
+    out = nhwc(prev).clone()
+    xd = nhwc(x)
+    il.y, il.addend, il.dact_x, il.dact_act = out.data_ptr(), out.data_ptr(), xd.data_ptr(), L.GA_ACT_SILU
+    il.N, il.H, il.W, il.C = N, 2 * h, 2 * h, Cin
+    L.run(il)
+    torch.cuda.synchronize()
+    close(nchw(out), gx + prev, 2e-4 if bf3 else 2e-5, f'sub-pixel transpose k{k}')
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)
