@@ -42,6 +42,29 @@ def conv_algorithmic_flops(plan):
     return total
 
 
+def conv_algorithmic_bytes(plan):
+    """bytes every ga_conv2d launch of a plan must move at least once: input(s), weights, output, act' source, addends"""
+    from gen_adversarial_amd import _lib as L
+    total = 0
+    for d in plan.descs:
+        if isinstance(d, L.ConvDesc):
+            pin, pout = d.N * d.Hi * d.Wi, d.N * d.Ho * d.Wo
+            total += 4 * (pin * (d.C1 + d.C2) + d.Cout * d.KH * d.KW * (d.C1 + d.C2) + pout * d.Cout)
+            total += 4 * pout * d.Cout * (bool(d.dact_x) + bool(d.addend2))
+            if d.addend:
+                total += 4 * d.Cout * (d.Ho * d.Wo if d.addend_bcast_n else pout // max(1, d.addend_rep))
+    return total
+
+
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)"""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_v3_summary.json')) as f:
+            return float(json.load(f)['conv_kernels']['hbm_bytes_per_launch'])
+    except Exception:
+        return None
+
+
 def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False, store=None):
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, init_nvae_state_dict
@@ -277,7 +300,11 @@ def main():
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
                          'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_traffic(),
+                         'traffic_note': 'HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE from the separate PMC passes '
+                                         'summarised in profiles/r01_pmc_v3_summary.json (same 512-row plans); algorithmic bytes '
+                                         'per launch beside it',
+                         'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                          'peak_note': ('dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-class product; achieved counts '
                                        'algorithmic (1x) flops' if args.precision == 'bf16x3' else 'fp32 MFMA peak'),
                          'achieved_over_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
