@@ -9,6 +9,7 @@ namespace ga {
 // epilogue on 4 consecutive channels of one output pixel (vector form)
 __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, const int co, floatx4 v, const int HoWo) {
     if (d.bias) v += *reinterpret_cast<const floatx4*>(d.bias + co);
+    if ((d.flags & GA_CONV_ADDEND_PRE_DACT) && d.addend) v += *reinterpret_cast<const floatx4*>(d.addend + (size_t)m * d.ldadd + co);
     if (d.dact_x) {
         floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)m * d.lddact + co);
         floatx4 ds = {1.f, 1.f, 1.f, 1.f};
@@ -19,10 +20,12 @@ __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, co
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
     }
-    if (d.addend) {
+    if (d.addend && !(d.flags & GA_CONV_ADDEND_PRE_DACT)) {
         size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
         if (d.addend_rep > 1) am = (size_t)((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
-        v += *reinterpret_cast<const floatx4*>(d.addend + am * d.ldadd + co);
+        floatx4 a = *reinterpret_cast<const floatx4*>(d.addend + am * d.ldadd + co);
+        if (d.flags & GA_CONV_ADDEND_RELU) { for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], 0.f); }
+        v += a;
     }
     if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + (size_t)m * d.ldadd2 + co);
     *reinterpret_cast<floatx4*>(d.y + (size_t)m * d.ldy + co) = v;
@@ -30,16 +33,18 @@ __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, co
 
 __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, const int co, float v, const int HoWo) {
     if (d.bias) v += d.bias[co];
+    if ((d.flags & GA_CONV_ADDEND_PRE_DACT) && d.addend) v += d.addend[(size_t)m * d.ldadd + co];
     if (d.dact_x) {
         float ds = 1.f, db = 0.f;
         if (d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
         const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
         v *= act_bwd_fast(u, d.dact_act) * ds;
     }
-    if (d.addend) {
+    if (d.addend && !(d.flags & GA_CONV_ADDEND_PRE_DACT)) {
         size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
         if (d.addend_rep > 1) am = (size_t)((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
-        v += d.addend[am * d.ldadd + co];
+        const float a = d.addend[am * d.ldadd + co];
+        v += (d.flags & GA_CONV_ADDEND_RELU) ? fmaxf(a, 0.f) : a;
     }
     if (d.addend2) v += d.addend2[(size_t)m * d.ldadd2 + co];
     d.y[(size_t)m * d.ldy + co] = v;
@@ -122,6 +127,8 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     floatx4 o = v[k] + bias4;
+                    const bool pre = (d.flags & GA_CONV_ADDEND_PRE_DACT) != 0;
+                    if (pre && d.addend) o += a1[k];
                     if (d.dact_x) {
                         const floatx4 uu = u[k] * ds4 + dt4;
                         if (d.dact_act == GA_ACT_SILU) {
@@ -132,7 +139,14 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                             for (int e = 0; e < 4; ++e) o[e] *= act_bwd_fast(uu[e], d.dact_act) * ds4[e];
                         }
                     }
-                    if (d.addend) o += a1[k];
+                    if (d.addend && !pre) {
+                        if (d.flags & GA_CONV_ADDEND_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] += fmaxf(a1[k][e], 0.f);
+                        } else {
+                            o += a1[k];
+                        }
+                    }
                     if (d.addend2) o += a2[k];
                     if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)(m0 + rb0 + k * ROWS) * d.ldy + co) = o;
                 }

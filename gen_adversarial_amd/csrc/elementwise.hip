@@ -398,6 +398,109 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const ga_maxpool2_desc d,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 2 / pad 1 max pool (torchvision ResNet stem) on pre-activation maps; backward gathers per input pixel
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ floatx4 ld4(const float* p) { return *reinterpret_cast<const floatx4*>(p); }
+
+__global__ void __launch_bounds__(256) maxpool3s2_kernel(const ga_maxpool3s2_desc d, const long total4) {
+    const int C4 = d.C / 4, Ho = d.H / 2, Wo = d.W / 2;
+    if (!d.backward) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+            const int c4 = (int)(i % C4); long p = i / C4;
+            const int wo = (int)(p % Wo); p /= Wo;
+            const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
+            floatx4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int kh = 0; kh < 3; ++kh) {
+                const int h = 2 * ho - 1 + kh;
+                if (h < 0 || h >= d.H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int w = 2 * wo - 1 + kw;
+                    if (w < 0 || w >= d.W) continue;
+                    const floatx4 v = ld4(d.x + (((size_t)n * d.H + h) * d.W + w) * d.C + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                }
+            }
+            *reinterpret_cast<floatx4*>(d.y + i * 4) = m;
+        }
+    } else {
+        // one thread per INPUT pixel x channel quad: the (at most 4) windows that contain it are re-scanned in the
+        // forward order; the pixel receives dy of a window iff it is that window's first maximum
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+            const int c4 = (int)(i % C4); long p = i / C4;
+            const int w = (int)(p % d.W); p /= d.W;
+            const int h = (int)(p % d.H); const int n = (int)(p / d.H);
+            const floatx4 me = ld4(d.x + (((size_t)n * d.H + h) * d.W + w) * d.C + 4 * c4);
+            floatx4 g = {0.f, 0.f, 0.f, 0.f};
+            const int ho0 = max(0, h / 2), ho1 = min(Ho - 1, (h + 1) / 2);                 // windows with 2ho-1 <= h <= 2ho+1
+            const int wo0 = max(0, w / 2), wo1 = min(Wo - 1, (w + 1) / 2);
+            for (int ho = ho0; ho <= ho1; ++ho)
+                for (int wo = wo0; wo <= wo1; ++wo) {
+                    // is (h, w) the first maximum of window (ho, wo)?  earlier positions must be strictly smaller is NOT the
+                    // rule: aten keeps an earlier element on ties (it replaces only on val > max), so "first maximum" = no
+                    // earlier element >= me and no later element > me
+                    unsigned win = 0xf;                                  // per channel of the quad
+                    for (int kh = 0; kh < 3; ++kh) {
+                        const int hh = 2 * ho - 1 + kh;
+                        if (hh < 0 || hh >= d.H) continue;
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int ww = 2 * wo - 1 + kw;
+                            if (ww < 0 || ww >= d.W || (hh == h && ww == w)) continue;
+                            const floatx4 v = ld4(d.x + (((size_t)n * d.H + hh) * d.W + ww) * d.C + 4 * c4);
+                            const bool earlier = hh < h || (hh == h && ww < w);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (earlier ? v[e] >= me[e] : v[e] > me[e]) win &= ~(1u << e);
+                        }
+                    }
+                    const floatx4 dy = ld4(d.dy + (((size_t)n * Ho + ho) * Wo + wo) * d.C + 4 * c4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (win & (1u << e)) g[e] += dy[e];
+                }
+            *reinterpret_cast<floatx4*>(d.dx + i * 4) = g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// global average pool with an activation prologue (torchvision ResNet avgpool after the last ReLU)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) avgpool_act_kernel(const ga_avgpool_act_desc d, const int nchunks) {
+    __shared__ floatx4 part[16][16];
+    const int tid = threadIdx.x, c4 = tid & 15, pl = tid >> 4;
+    const int n = blockIdx.x / nchunks, chunk = blockIdx.x % nchunks;
+    const int c = chunk * 64 + 4 * c4;
+    const float inv = 1.0f / (float)d.P;
+    if (!d.backward) {
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (c < d.C)
+            for (int p = pl; p < d.P; p += 16) {
+                floatx4 v = ld4(d.x + ((size_t)n * d.P + p) * d.C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += act_fwd(v[e], d.act);
+            }
+        part[pl][c4] = acc;
+        __syncthreads();
+        if (pl == 0 && c < d.C) {
+            floatx4 s = part[0][c4];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) s += part[i][c4];
+            *reinterpret_cast<floatx4*>(d.y + (size_t)n * d.C + c) = s * inv;
+        }
+    } else if (c < d.C) {
+        const floatx4 g = ld4(d.dy + (size_t)n * d.C + c) * inv;
+        for (int p = pl; p < d.P; p += 16) {
+            const size_t o = ((size_t)n * d.P + p) * d.C + c;
+            const floatx4 v = ld4(d.x + o);
+            floatx4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = g[e] * act_bwd(v[e], d.act);
+            *reinterpret_cast<floatx4*>(d.dx + o) = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // image boundary: NCHW <-> NHWC, EoT repeat, input noise + clamp (abstract_models.py:129-143; wrappers.py:20)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d, const long total) {
@@ -627,6 +730,28 @@ extern "C" int ga_maxpool2(const ga_maxpool2_desc* d, void* s) {
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
     const long total4 = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_maxpool3s2(const ga_maxpool3s2_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (((d->H | d->W) & 1) || (d->C % 4)) return GA_E_UNSUPPORTED;
+    if (!d->backward && !d->y) return GA_E_BADARG;
+    if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    const long total4 = d->backward ? (long)d->N * d->H * d->W * (d->C / 4) : (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_avgpool_act(const ga_avgpool_act_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && !d->y) return GA_E_BADARG;
+    if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    const int nchunks = (d->C + 63) / 64;
+    hipLaunchKernelGGL(avgpool_act_kernel, dim3(d->N * nchunks), dim3(256), 0, (hipStream_t)s, *d, nchunks);
     return check_launch();
 }
 

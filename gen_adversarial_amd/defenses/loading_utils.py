@@ -3,9 +3,11 @@ Checkpoint ingestion with the reference's file layouts (src/defenses/loading_uti
 holders instead of nn.Modules: the arithmetic lives in libga_ops, not in torch modules.
 
   load_Vgg11(path, device, n_classes=100)   ckpt['state_dict'] with keys model.features.N.*, model.classifier.{0,1,3}.*
+  load_ResNet50(path, device, n_classes=2)  ckpt['state_dict'] with torchvision resnet50 keys under `model.` and the
+                                            projector head model.fc.{0,1,3}.* (loading_utils.py:10-16)
   load_NVAE(path, device, temperature)      ckpt['configuration'] {'autoencoder': cfg, 'resolution': (C,H,W)} and
                                             ckpt[f'state_dict_temp={temperature}']
-E4E / Style-Transformer / ResNet loaders are the "next" rows of SURVEY.md §8 and raise NotImplementedError.
+E4E / Style-Transformer / ResNeXt loaders are the "next" rows of SURVEY.md §8 and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -15,6 +17,7 @@ from typing import Dict, Tuple
 import torch
 
 from ..nvae_spec import build_spec
+from ..resnet_spec import RESNET50_BLOCKS, build_resnet_spec
 from ..vgg_spec import build_vgg_spec
 
 
@@ -29,6 +32,24 @@ class VggWeights:
         return build_vgg_spec(self.n_classes, self.width_div)
 
     def to(self, device):          # nn.Module-like no-ops so that caller code written for the reference keeps working
+        return self
+
+    def eval(self):
+        return self
+
+
+@dataclass
+class ResNetWeights:
+    state_dict: Dict[str, torch.Tensor]
+    n_classes: int
+    width_div: int = 1
+    blocks: Tuple[int, ...] = RESNET50_BLOCKS
+
+    @property
+    def spec(self):
+        return build_resnet_spec(self.n_classes, self.width_div, self.blocks)
+
+    def to(self, device):
         return self
 
     def eval(self):
@@ -79,7 +100,14 @@ def _next(name):
     return fn
 
 
-load_ResNet50 = _next('load_ResNet50')
+def load_ResNet50(path: str, device: str, n_classes: int = 2) -> ResNetWeights:
+    """src/defenses/loading_utils.py:10-16.  Width and depth are read off the tensors, so reduced test checkpoints load too."""
+    sd = _torch_load(path)['state_dict']
+    width_div = 64 // sd['model.conv1.weight'].shape[0]
+    blocks = tuple(1 + max(int(k.split('.')[2]) for k in sd if k.startswith(f'model.layer{i}.')) for i in (1, 2, 3, 4))
+    return ResNetWeights(sd, sd['model.fc.3.weight'].shape[0] if n_classes is None else n_classes, width_div, blocks)
+
+
 load_ResNext50 = _next('load_ResNext50')
 load_E4EStyleGan = _next('load_E4EStyleGan')
 load_TranStyleGan = _next('load_TranStyleGan')

@@ -1,14 +1,14 @@
 """
 Concrete classifier / defender classes with the reference's names and constructor signatures
-(src/defenses/ours/models.py:17-353).  The CelebA-identities pair (VGG-11 classifier + NVAE defender) is the built
-path; the gender (ResNet-50 + e4e/StyleGAN2) and cars (ResNeXt-50 + Style-Transformer) pairs are "next" rows.
+(src/defenses/ours/models.py:17-353).  The CelebA-identities pair (VGG-11 classifier + NVAE defender) and the gender
+ResNet-50 classifier are built; the e4e/StyleGAN2 purifier and the cars pair (ResNeXt-50 + Style-Transformer) are "next" rows.
 """
 from __future__ import annotations
 
 import torch
 
 from ...engine import Engine
-from ..loading_utils import load_NVAE, load_Vgg11, NVAEWeights
+from ..loading_utils import load_NVAE, load_ResNet50, load_Vgg11, NVAEWeights
 from .abstract_models import BaseClassificationModel, MLVGMDefenseModel
 
 
@@ -21,6 +21,18 @@ class CelebaIdentityClassifier(BaseClassificationModel, torch.nn.Module):
 
     def load_classifier(self, model_path: str, device: str):
         return load_Vgg11(model_path, device)
+
+
+class CelebaGenderClassifier(BaseClassificationModel, torch.nn.Module):
+    """CelebA-HQ 256 gender ResNet-50 (models.py:17-35)."""
+
+    def __init__(self, model_path: str, device: str):
+        torch.nn.Module.__init__(self)
+        self.image_size = 256
+        BaseClassificationModel.__init__(self, model_path, device, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+
+    def load_classifier(self, model_path: str, device: str):
+        return load_ResNet50(model_path, device)
 
 
 class NVAEDefenseModel(MLVGMDefenseModel, torch.nn.Module):
@@ -54,7 +66,6 @@ def _next(name, what):
     return _NotBuilt
 
 
-CelebaGenderClassifier = _next('CelebaGenderClassifier', 'ResNet-50 classifier (models.py:17-35)')
 CarsTypeClassifier = _next('CarsTypeClassifier', 'ResNeXt-50 classifier (models.py:59-77)')
 E4EStyleGanDefenseModel = _next('E4EStyleGanDefenseModel', 'e4e + StyleGAN2 purifier (models.py:80-132)')
 TransStyleGanDefenseModel = _next('TransStyleGanDefenseModel', 'Style-Transformer purifier (models.py:277-353)')

@@ -22,6 +22,7 @@ import torch
 from . import _lib as L
 from . import folding as F
 from .nvae_spec import DecCellSpec, EncCellSpec, NVAESpec, build_spec
+from .resnet_spec import ResNetSpec
 from .vgg_spec import VggSpec
 
 RES_SCALE = 0.1          # `0.1 * self.residual(x)` — architecture.py:133,183
@@ -208,8 +209,9 @@ class Engine:
                 addend = target.g
             else:
                 addend2 = target.g
-        self.conv(self.bwd, name, x, w, target.g, addend=addend, addend2=addend2, **kw)
+        d = self.conv(self.bwd, name, x, w, target.g, addend=addend, addend2=addend2, **kw)
         target.g_written = True
+        return d
 
     def grad_conv_up2(self, name, x, wts, key, target: Act, *, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0):
         """Backward-to-input of a stride-2 conv into target.g (twice the resolution of x) by sub-pixel decomposition:
@@ -416,7 +418,7 @@ class Engine:
 
         # ---- classifier
         n_nvae_steps = len(self._bwd_steps)
-        self.logits = self._build_vgg(vgg_sd, img)
+        self.logits = (self._build_resnet if isinstance(self.vspec, ResNetSpec) else self._build_vgg)(vgg_sd, img)
 
         # ---- emit the backward plan: reverse registration order (classifier part first)
         self.bwd_split = 0
@@ -773,6 +775,99 @@ class Engine:
             feat.g_written = True
         self._bwd_steps.append(bwd_head)
         return out.t.view(R, vs.n_classes)
+
+    # ------------------------------------------------------------------------------------------------ ResNet-50
+    def _build_resnet(self, rsd, img: Act) -> torch.Tensor:
+        """ResNet.forward (src/classifier/model.py:10-28; torchvision resnet50, resnet_spec.py) on the NHWC image:
+        normalisation as the stem's prologue affine, every conv with its BatchNorm folded, residual sums stored
+        PRE-activation (ReLU is the consumers' prologue, the identity branch adds relu(sum) through
+        GA_CONV_ADDEND_RELU, and its cotangent passes the same relu' as the conv branch, GA_CONV_ADDEND_PRE_DACT)."""
+        rs, R = self.vspec, self.rows
+        norm = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
+        two, mone = norm['two'], norm['mone']
+        stem = self.devd('resnet.stem', lambda: F.fold_resnet_stem(rsd, IMG_LD))
+        c1 = Act(self, R, img.h // 2, img.w // 2, rs.stem_channels, 'resnet.conv1')
+        self.conv(self.fwd, 'resnet.conv1', img.t, stem['w'], c1.t, bias=stem['b'], K=7, sn=2, pad=3, pro_scale=two, pro_shift=mone)
+        p1 = Act(self, R, c1.h // 2, c1.w // 2, rs.stem_channels, 'resnet.pool')
+        m = L.Maxpool3s2Desc()
+        m.x, m.y, m.N, m.H, m.W, m.C, m.backward = _ptr(c1.t), _ptr(p1.t), R, c1.h, c1.w, c1.c, 0
+        self.fwd.add(m, 'resnet.maxpool')
+
+        def bwd_stem():
+            b = L.Maxpool3s2Desc()
+            b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = _ptr(c1.t), _ptr(p1.g), _ptr(c1.g), R, c1.h, c1.w, c1.c, 1
+            self.bwd.add(b, 'resnet.maxpool^T')
+            c1.g_written = True
+            self.grad_conv('resnet.conv1^T', c1.g, stem['w_bwd'], img, K=7, sn=1, sd=2, pad=3,
+                           dact_x=img.t, dact_scale=two, dact_shift=mone, dact_act=L.GA_ACT_NONE)
+        self._bwd_steps.append(bwd_stem)
+
+        cur = p1
+        for blk in rs.blocks:
+            cur = self._resnet_block(rsd, blk, cur)
+
+        head = self.devd('resnet.head', lambda: F.fold_resnet_head(rsd))
+        last = cur
+        pooled = Act(self, R, 1, 1, last.c, 'resnet.avgpool')
+        a = L.AvgpoolActDesc()
+        a.x, a.y, a.N, a.P, a.C, a.act, a.backward = _ptr(last.t), _ptr(pooled.t), R, last.h * last.w, last.c, L.GA_ACT_RELU, 0
+        self.fwd.add(a, 'resnet.avgpool')
+        h1 = Act(self, R, 1, 1, last.c, 'resnet.fc0')
+        self.conv(self.fwd, 'resnet.fc0', pooled.t, head['w_h'], h1.t, bias=head['b_h'], K=1)
+        out = Act(self, R, 1, 1, rs.n_classes, 'resnet.logits')
+        self.conv(self.fwd, 'resnet.fc3', h1.t, head['w_o'], out.t, bias=head['b_o'], K=1, pro_act=L.GA_ACT_RELU)
+        self.dlogits = out.g
+        out.g_written = True
+
+        def bwd_head():
+            self.grad_conv('resnet.fc3^T', out.g, head['w_o_bwd'], h1, K=1, dact_x=h1.t, dact_act=L.GA_ACT_RELU)
+            self.grad_conv('resnet.fc0^T', h1.g, head['w_h_bwd'], pooled, K=1)
+            b = L.AvgpoolActDesc()
+            b.x, b.dy, b.dx, b.N, b.P, b.C, b.act, b.backward = (_ptr(last.t), _ptr(pooled.g), _ptr(last.g), R, last.h * last.w,
+                                                                 last.c, L.GA_ACT_RELU, 1)
+            assert not last.g_written
+            self.bwd.add(b, 'resnet.avgpool^T')
+            last.g_written = True
+        self._bwd_steps.append(bwd_head)
+        return out.t.view(R, rs.n_classes)
+
+    def _resnet_block(self, rsd, blk, s_in: Act) -> Act:
+        """torchvision Bottleneck (1x1 -> 3x3 (stride) -> 1x1, + identity or 1x1-strided shortcut, ReLU after the sum)"""
+        p, R = blk.prefix.replace('model.', 'resnet.'), self.rows
+        wts = self.devd(p, lambda: F.fold_resnet_block(rsd, blk))
+        h, w, st = s_in.h, s_in.w, blk.stride
+        t1 = Act(self, R, h, w, blk.width, p + '.t1')
+        t2 = Act(self, R, h // st, w // st, blk.width, p + '.t2')
+        s_out = Act(self, R, h // st, w // st, blk.cout, p + '.sum')
+        self.conv(self.fwd, p + '.conv1', s_in.t, wts['w1'], t1.t, bias=wts['b1'], K=1, pro_act=L.GA_ACT_RELU)
+        self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, sn=st, pad=1, pro_act=L.GA_ACT_RELU)
+        if blk.downsample:
+            ds = Act(self, R, h // st, w // st, blk.cout, p + '.shortcut')
+            self.conv(self.fwd, p + '.downsample', s_in.t, wts['wd'], ds.t, bias=wts['bd'], K=1, sn=st, pad=0, pro_act=L.GA_ACT_RELU)
+            self.conv(self.fwd, p + '.conv3', t2.t, wts['w3'], s_out.t, bias=wts['b3'], K=1, pro_act=L.GA_ACT_RELU, addend=ds.t)
+        else:
+            d = self.conv(self.fwd, p + '.conv3', t2.t, wts['w3'], s_out.t, bias=wts['b3'], K=1, pro_act=L.GA_ACT_RELU, addend=s_in.t)
+            d.flags = L.GA_CONV_ADDEND_RELU
+
+        def backward():
+            self.grad_conv(p + '.conv3^T', s_out.g, wts['w3_bwd'], t2, K=1, dact_x=t2.t, dact_act=L.GA_ACT_RELU)
+            if st == 1:
+                self.grad_conv(p + '.conv2^T', t2.g, wts['w2_bwd'], t1, K=3, pad=1, dact_x=t1.t, dact_act=L.GA_ACT_RELU)
+            else:
+                self.grad_conv_up2(p + '.conv2^T', t2.g, wts, 'w2_sub', t1, dact_x=t1.t, dact_act=L.GA_ACT_RELU)
+            if blk.downsample:
+                self.grad_conv(p + '.conv1^T', t1.g, wts['w1_bwd'], s_in, K=1, dact_x=s_in.t, dact_act=L.GA_ACT_RELU)
+                if st == 1:
+                    self.grad_conv(p + '.downsample^T', s_out.g, wts['wd_bwd'], s_in, K=1, dact_x=s_in.t, dact_act=L.GA_ACT_RELU)
+                else:
+                    self.grad_conv_up2(p + '.downsample^T', s_out.g, wts, 'wd_sub', s_in, dact_x=s_in.t, dact_act=L.GA_ACT_RELU)
+            else:       # identity shortcut: (W1^T dt1 + d s_out) * relu'(s_in)
+                assert not s_in.g_written
+                d = self.grad_conv(p + '.conv1^T', t1.g, wts['w1_bwd'], s_in, K=1, primary=s_out.g,
+                                   dact_x=s_in.t, dact_act=L.GA_ACT_RELU)
+                d.flags = L.GA_CONV_ADDEND_PRE_DACT
+        self._bwd_steps.append(backward)
+        return s_out
 
     # ------------------------------------------------------------------------------------------------ run
     def set_alphas(self, alphas: Sequence[float]):

@@ -5,8 +5,8 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `args.attacks` and attaches `defense_model.get_purified`.
 
 Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only), 'ablation' (noise / blur) and 'ours'
-(NVAE purifier), with the
-reference's attack set (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
+(NVAE purifier); experiment 'gender' (ResNet-50 on 256x256) with 'base' | 'trades' | 'ablation'; the reference's
+attack sets (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
 Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
 """
 from argparse import Namespace
@@ -16,7 +16,7 @@ import yaml
 from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
 from ..defenses.ablations.models import GaussianBlurDefenseModel, GaussianNoiseDefenseModel
-from ..defenses.ours.models import CelebaIdentityClassifier, NVAEDefenseModel
+from ..defenses.ours.models import CelebaGenderClassifier, CelebaIdentityClassifier, E4EStyleGanDefenseModel, NVAEDefenseModel
 from ..defenses.wrappers import EoTWrapper
 
 
@@ -37,8 +37,20 @@ def load(args: Namespace):
         args.pgd = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)
         base_classifier = CelebaIdentityClassifier(d_params.classifier_path, args.device)
         hl_instance = NVAEDefenseModel
-    elif args.experiment in ('gender', 'cars'):
-        raise NotImplementedError(f"experiment '{args.experiment}' (StyleGAN purifiers) is a next row, not built yet")
+    elif args.experiment == 'gender':
+        # ResNet-50 classifier (load_defense.py:27-41): built for defense_type base / trades / ablation; the e4e +
+        # StyleGAN2 purifier of 'ours' is a next row (its constructor raises NotImplementedError)
+        args.image_size = 256
+        args.attacks = {
+            'deepfool': DeepFool(num_classes=2, overshoot=0.01, max_iter=1024),
+            'c&w': CW(c=64., kappa=0.01, steps=1024, lr=1e-3, n_restarts=8, early_stopping_steps=32),
+            'autoattack': AutoAttack()
+        }
+        args.pgd = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)
+        base_classifier = CelebaGenderClassifier(d_params.classifier_path, args.device)
+        hl_instance = E4EStyleGanDefenseModel
+    elif args.experiment == 'cars':
+        raise NotImplementedError("experiment 'cars' (ResNeXt-50 + Style-Transformer) is a next row, not built yet")
     else:
         raise NotImplementedError
 

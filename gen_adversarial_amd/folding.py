@@ -218,3 +218,51 @@ def nf_constant_shift(sd: SD, key: str, num_nf_cells: int, num_latent: int) -> t
                 raise NotImplementedError('normalizing-flow cell with a non-empty 1x1 mask: not built')
             c += sd[f'{p}.bias'].double()
     return c
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ResNet-50 (src/classifier/model.py:10-28; torchvision topology restated in resnet_spec.py)
+# ---------------------------------------------------------------------------------------------------------------
+
+def _conv_bn64(sd: SD, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """bias-free conv followed by eval-mode BatchNorm2d -> (folded weights [Cout,Cin,k,k] float64, bias [Cout])"""
+    s, t = bn_affine64(sd, bn)
+    return sd[f'{conv}.weight'].double() * s.view(-1, 1, 1, 1), t
+
+
+def fold_resnet_stem(sd: SD, ld: int) -> dict:
+    w, b = _conv_bn64(sd, 'model.conv1', 'model.bn1')
+    return pad_image_conv({'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(b)}, 3, ld)
+
+
+def fold_resnet_block(sd: SD, blk) -> dict:
+    p = blk.prefix
+    w1, b1 = _conv_bn64(sd, f'{p}.conv1', f'{p}.bn1')
+    w2, b2 = _conv_bn64(sd, f'{p}.conv2', f'{p}.bn2')
+    w3, b3 = _conv_bn64(sd, f'{p}.conv3', f'{p}.bn3')
+    out = {'w1': f32(conv_fwd_layout(w1)), 'w1_bwd': f32(conv_bwd_layout(w1)), 'b1': f32(b1),
+           'w2': f32(conv_fwd_layout(w2)), 'b2': f32(b2),
+           'w3': f32(conv_fwd_layout(w3)), 'w3_bwd': f32(conv_bwd_layout(w3)), 'b3': f32(b3)}
+    if blk.stride == 1:
+        out['w2_bwd'] = f32(conv_bwd_layout(w2))
+    else:
+        for (a, b), (wm, kh, kw) in subpixel_weights(w2).items():
+            out[f'w2_sub{a}{b}'] = wm
+    if blk.downsample:
+        wd, bd = _conv_bn64(sd, f'{p}.downsample.0', f'{p}.downsample.1')
+        out['wd'], out['bd'] = f32(conv_fwd_layout(wd)), f32(bd)
+        if blk.stride == 1:
+            out['wd_bwd'] = f32(conv_bwd_layout(wd))
+        else:
+            for (a, b), (wm, kh, kw) in subpixel_weights(wd).items():
+                out[f'wd_sub{a}{b}'] = wm
+    return out
+
+
+def fold_resnet_head(sd: SD) -> dict:
+    """Linear(d, d, bias=False) + BatchNorm1d folded, then Linear(d, n) — src/classifier/model.py:19-24."""
+    s, t = bn_affine64(sd, 'model.fc.1')
+    w0 = sd['model.fc.0.weight'].double() * s.view(-1, 1)
+    w3 = sd['model.fc.3.weight']
+    return {'w_h': f32(w0), 'w_h_bwd': f32(w0.t()), 'b_h': f32(t),
+            'w_o': f32(w3), 'w_o_bwd': f32(w3.t()), 'b_o': f32(sd['model.fc.3.bias'])}

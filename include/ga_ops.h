@@ -30,6 +30,11 @@ extern "C" {
 #define GA_E_LAUNCH     -4   /* hipLaunch failed (see ga_last_hip_error) */
 
 enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3 };
+/* ga_conv_desc.flags — residual networks that keep PRE-activation sums (torchvision Bottleneck: out = relu(f(x) + identity)):
+ *   GA_CONV_ADDEND_RELU     forward : y = ... + relu(addend)            (the identity branch is relu of the stored pre-activation)
+ *   GA_CONV_ADDEND_PRE_DACT backward: y = (acc + addend) * act'(dact_x) (+ addend2): the identity branch's cotangent passes
+ *                                      through the same act' as the convolution branch's */
+enum ga_conv_flags { GA_CONV_ADDEND_RELU = 1, GA_CONV_ADDEND_PRE_DACT = 2 };
 
 /* ------------------------------------------------------------------------------------------------------------------
  * ga_conv2d — dense convolution as an fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
@@ -83,7 +88,7 @@ typedef struct ga_conv_desc {
                                               product on the bf16 matrix cores (~2e-5 relative), else exact fp32 MFMA. */
     int addend_rep;                        /* > 1: addend has N/addend_rep rows, row n reads addend row n / addend_rep
                                               (EoT replicas sharing one encoder feature map) */
-    int _reserved2;
+    int flags;                             /* GA_CONV_* bits below */
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
@@ -197,6 +202,22 @@ typedef struct ga_maxpool2_desc {
 } ga_maxpool2_desc;
 int ga_maxpool2(const ga_maxpool2_desc* d, void* stream);
 
+/* 3x3 / stride 2 / pad 1 max pool (torchvision ResNet stem, resnet.py `self.maxpool`), on pre-activation maps (ReLU
+ * commutes with max).  x: [N,H,W,C], y: [N,H/2,W/2,C] (H, W even).  backward: dx[p] = sum of dy over the windows whose
+ * first maximal element in scan order is p (aten::max_pool2d_with_indices keeps the first), gathered per input pixel:
+ * deterministic, no atomics. */
+typedef struct ga_maxpool3s2_desc {
+    const float* x; float* y; const float* dy; float* dx; int N, H, W, C; int backward;
+} ga_maxpool3s2_desc;
+int ga_maxpool3s2(const ga_maxpool3s2_desc* d, void* stream);
+
+/* Global average pool with an activation prologue (torchvision ResNet `avgpool` after the last block's ReLU):
+ * forward  y[n,c] = mean_p act(x[n,p,c]);  backward dx[n,p,c] = dy[n,c] / P * act'(x[n,p,c]).  x: [N,P,C], C % 4 == 0. */
+typedef struct ga_avgpool_act_desc {
+    const float* x; float* y; const float* dy; float* dx; int N, P, C; int act; int backward; int _reserved;
+} ga_avgpool_act_desc;
+int ga_avgpool_act(const ga_avgpool_act_desc* d, void* stream);
+
 /* Image boundary: NCHW [N,3,H,W] in [0,1] <-> NHWC with MLVGMDefenseModel.add_gaussian_noise
  * (abstract_models.py:129-143): out = clamp(x[n / rep] + noise * noise_coef[n], 0, 1); `rep` folds EoTWrapper's
  * x.repeat(eot,1,1,1) (wrappers.py:20).  noise may be NULL.  backward: dx[n,c,h,w] = dy_nhwc * 1[0 <= pre <= 1]. */
@@ -257,7 +278,8 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
  * ------------------------------------------------------------------------------------------------------------------ */
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
-                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14 };
+                  GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
+                  GA_OP_AVGPOOL_ACT = 16 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -267,6 +289,7 @@ typedef struct ga_op {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
+        ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -49,6 +49,36 @@ def vgg_forward(sd: SD, spec: VggSpec, x: torch.Tensor) -> torch.Tensor:
     return F.linear(x, sd['model.classifier.3.weight'], sd['model.classifier.3.bias'])
 
 
+def resnet_forward(sd: SD, spec, x: torch.Tensor) -> torch.Tensor:
+    """ResNet.forward — src/classifier/model.py:10-28: torchvision resnet50 (published definition, see
+    gen_adversarial_amd/resnet_spec.py) with the projector head of :19-24, eval mode."""
+    def bn(p, t):
+        return F.batch_norm(t, sd[f'{p}.running_mean'], sd[f'{p}.running_var'], sd[f'{p}.weight'], sd[f'{p}.bias'],
+                            False, 0.0, 1e-5)
+    x = F.relu(bn('model.bn1', F.conv2d(x, sd['model.conv1.weight'], stride=2, padding=3)))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for b in spec.blocks:
+        p = b.prefix
+        o = F.relu(bn(f'{p}.bn1', F.conv2d(x, sd[f'{p}.conv1.weight'])))
+        o = F.relu(bn(f'{p}.bn2', F.conv2d(o, sd[f'{p}.conv2.weight'], stride=b.stride, padding=1)))
+        o = bn(f'{p}.bn3', F.conv2d(o, sd[f'{p}.conv3.weight']))
+        idt = bn(f'{p}.downsample.1', F.conv2d(x, sd[f'{p}.downsample.0.weight'], stride=b.stride)) if b.downsample else x
+        x = F.relu(o + idt)
+    x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
+    x = F.linear(x, sd['model.fc.0.weight'])
+    x = F.relu(F.batch_norm(x, sd['model.fc.1.running_mean'], sd['model.fc.1.running_var'], sd['model.fc.1.weight'],
+                            sd['model.fc.1.bias'], False, 0.0, 1e-5))
+    return F.linear(x, sd['model.fc.3.weight'], sd['model.fc.3.bias'])
+
+
+def resnet_classifier_call(sd: SD, spec, batch: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+    """BaseClassificationModel.__call__ with the ResNet-50 of CelebaGenderClassifier — abstract_models.py:53-62,
+    ours/models.py:17-35."""
+    m = torch.tensor(mean, dtype=batch.dtype).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=batch.dtype).view(1, 3, 1, 1)
+    return resnet_forward(sd, spec, (batch - m) / s)
+
+
 def classifier_call(sd: SD, spec: VggSpec, batch: torch.Tensor, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
     """BaseClassificationModel.__call__ — abstract_models.py:53-62 with the CelebaIdentityClassifier
     constants (models.py:45-47)."""

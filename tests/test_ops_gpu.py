@@ -515,6 +515,69 @@ def test_maxpool(N, H, Cc):
     close(nchw(dx), gx, 0, 'maxpool bwd')
 
 
+@pytest.mark.parametrize('N,H,W,Cc', [(2, 8, 8, 8), (3, 16, 12, 20), (1, 6, 4, 4)])
+def test_maxpool3s2(N, H, W, Cc):
+    """3x3 / stride 2 / pad 1 max pool and its gather-form backward against torch (ties included: quantised inputs)"""
+    x = (g(N, Cc, H, W, seed=1) * 2).round() / 2          # many exact ties -> exercises the first-maximum rule
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    cot = g(*ref.shape, seed=2)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    xd = nhwc(x)
+    y = torch.empty(N, H // 2, W // 2, Cc, device=DEV)
+    d = L.Maxpool3s2Desc()
+    d.x, d.y, d.N, d.H, d.W, d.C, d.backward = xd.data_ptr(), y.data_ptr(), N, H, W, Cc, 0
+    L.run(d)
+    close(nchw(y), ref, 0, 'maxpool3s2 fwd')
+    dy, dx = nhwc(cot), torch.full((N, H, W, Cc), float('nan'), device=DEV)
+    b = L.Maxpool3s2Desc()
+    b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = xd.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, 1
+    L.run(b)
+    torch.cuda.synchronize()
+    close(nchw(dx), gx, 1e-6, 'maxpool3s2 bwd')
+
+
+def test_avgpool_act():
+    N, P, Cc = 3, 20, 72
+    x = g(N, P, Cc, seed=1)
+    xr = x.clone().requires_grad_(True)
+    ref = F.relu(xr).mean(dim=1)
+    cot = g(N, Cc, seed=2)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    xd, y, dy, dx = x.to(DEV), torch.empty(N, Cc, device=DEV), cot.to(DEV), torch.empty(N, P, Cc, device=DEV)
+    d = L.AvgpoolActDesc()
+    d.x, d.y, d.N, d.P, d.C, d.act, d.backward = xd.data_ptr(), y.data_ptr(), N, P, Cc, L.GA_ACT_RELU, 0
+    L.run(d)
+    b = L.AvgpoolActDesc()
+    b.x, b.dy, b.dx, b.N, b.P, b.C, b.act, b.backward = xd.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, P, Cc, L.GA_ACT_RELU, 1
+    L.run(b)
+    torch.cuda.synchronize()
+    close(y.cpu(), ref, 1e-6, 'avgpool fwd')
+    close(dx.cpu(), gx, 1e-6, 'avgpool bwd')
+
+
+@pytest.mark.parametrize('Cout,splits', [(64, 1), (20, 1), (64, 2)])
+def test_conv_residual_flags(Cout, splits):
+    """GA_CONV_ADDEND_RELU (y = conv + relu(addend)) and GA_CONV_ADDEND_PRE_DACT (y = (conv + addend) * act'(u)) in the
+    vector, scalar and split-K epilogues"""
+    N, H, Cin = 2, 8, 32
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, 1, 1, seed=2, scale=0.2)
+    a = g(N, Cout, H, H, seed=3)
+    u = g(N, Cout, H, H, seed=4)
+    conv = F.conv2d(x, w)
+    ws = torch.empty(max(1, splits * N * H * H * Cout), device=DEV)
+    kw = dict(splits=splits)
+    if splits > 1:
+        kw.update(ws=ws, ws_floats=ws.numel())
+    y = torch.empty(N, H, H, Cout, device=DEV)
+    run_conv(nhwc(x), fwd_w(w), y, 1, addend=nhwc(a), ldadd=Cout, flags=L.GA_CONV_ADDEND_RELU, **kw)
+    close(nchw(y), conv + F.relu(a), 2e-5, 'addend relu')
+    run_conv(nhwc(x), fwd_w(w), y, 1, addend=nhwc(a), ldadd=Cout, dact_x=nhwc(u), lddact=Cout, dact_act=3,
+             flags=L.GA_CONV_ADDEND_PRE_DACT, **kw)
+    close(nchw(y), (conv + a) * (u > 0).float(), 2e-5, 'addend before act\'')
+
+
 def test_image_io():
     B, rep, H = 2, 3, 8
     N = B * rep

@@ -1,0 +1,81 @@
+"""
+GPU parity of the ResNet-50 classifier path (CelebaGenderClassifier, src/defenses/ours/models.py:17-35,
+src/classifier/model.py:10-28) against the CPU oracle: logits and input gradient, in both precisions, on a reduced
+width/depth network (every block kind: identity, projection, strided projection) and on the full ResNet-50 at 256x256.
+torchvision's topology is restated from its published definition (absent from the image): parity is pinned by the oracle
+restatement only.  Tolerance: 1e-3 absolute on logits as for the other classifier.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd.engine import Engine   # noqa: E402
+from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict   # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _check(width_div, blocks, res, rows, precision, tol):
+    from oracle import defender_oracle as D
+    spec = build_resnet_spec(2, width_div, blocks)
+    sd = init_resnet_state_dict(2, width_div, 7, blocks)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(rows, 3, res, res, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    logits = D.resnet_classifier_call(sd, spec, xr)
+    cot = torch.randn(logits.shape, generator=gen)
+    (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
+    eng = Engine(None, None, (3, res, res), sd, spec, rows=rows, rep=1, alphas=[], device=DEV, precision=precision)
+    eng.x_in.copy_(x.to(DEV))
+    eng.forward()
+    e_l = (eng.logits.cpu() - logits).abs().max().item()
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    diff = (eng.dx.cpu() - gx).double()
+    rel = (diff.norm() / gx.double().norm()).item()
+    print(f'resnet wd{width_div} {blocks} {res}px [{precision}]: logits err {e_l:.2e} (|logits| {logits.abs().max().item():.2f}) '
+          f'grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
+    assert e_l < tol
+    assert rel < 2e-2            # the stem's max pool and the ReLUs make the gradient discontinuous at near-ties
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])
+def test_reduced_resnet_matches_oracle(precision, tol):
+    _check(4, (2, 2, 2, 1), 64, 3, precision, tol)
+
+
+def test_full_resnet50_matches_oracle():
+    _check(1, (3, 4, 6, 3), 256, 2, 'bf16x3', 1e-3)
+
+
+def test_gender_classifier_api(tmp_path):
+    """CelebaGenderClassifier through load(args): checkpoint layout of loading_utils.py:10-16, base defense"""
+    from argparse import Namespace
+    import yaml
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    blocks, wd = (1, 1, 1, 1), 8
+    sd = init_resnet_state_dict(2, wd, 5, blocks)
+    torch.save({'state_dict': sd}, tmp_path / 'resnet.pt')
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(tmp_path / 'resnet.pt'), 'autoencoder_path': '', 'interpolation_alphas': [0.5] * 18,
+                        'alpha_attenuation': 1.0, 'initial_noise_eps': 0.0, 'gaussian_blur_input': False}, f)
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='base', eot_steps=1, device=DEV))
+    assert args.image_size == 256 and set(args.attacks) == {'deepfool', 'c&w', 'autoattack'}
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    ref = D.resnet_classifier_call(sd, build_resnet_spec(2, wd, blocks), x)
+    assert (out.detach().cpu() - ref).abs().max().item() < 1e-3
+    (g,) = torch.autograd.grad(out[:, 1].sum(), [xd])
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
+    assert model.get_purified(x) is x
+    with pytest.raises(NotImplementedError):
+        load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=1, device=DEV))
