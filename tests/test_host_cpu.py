@@ -190,3 +190,34 @@ def test_nf_cells_reduce_to_a_constant_shift():
     sd['nf_cells.nf_0:0.0.cell1.layers.4.mask'].fill_(1.0)
     with pytest.raises(NotImplementedError):
         folding.nf_constant_shift(sd, '0:0', 3, 4)
+
+
+def test_resnet_plans_build_and_checkpoint_layout(tmp_path):
+    """ResNet-50 row (a13): the loader reads width/depth off a checkpoint in the reference layout
+    (loading_utils.py:10-16), the plans build (dry run) for every block kind, and the BN fold is exact."""
+    import torch
+    import torch.nn.functional as TF
+    from gen_adversarial_amd import folding
+    from gen_adversarial_amd.defenses.loading_utils import load_ResNet50
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    blocks, wd = (2, 1, 2, 1), 8
+    sd = init_resnet_state_dict(2, wd, 3, blocks)
+    torch.save({'state_dict': sd}, tmp_path / 'r.pt')
+    w = load_ResNet50(str(tmp_path / 'r.pt'), 'cpu')
+    assert (w.width_div, w.blocks, w.n_classes) == (wd, blocks, 2)
+    spec = w.spec
+    assert [b.stride for b in spec.blocks] == [1, 1, 2, 2, 1, 2] and [b.downsample for b in spec.blocks] == [True, False, True, True, False, True]
+    full = build_resnet_spec(2)
+    assert len(full.blocks) == 16 and full.feat_channels == 2048 and full.blocks[3].cin == 256 and full.blocks[3].stride == 2
+    eng = Engine(None, None, (3, 64, 64), sd, spec, rows=2, rep=1, alphas=[], device='cpu', dry_run=True)
+    kinds = {type(d).__name__ for d in eng.fwd.descs} | {type(d).__name__ for d in eng.bwd.descs}
+    assert {'Maxpool3s2Desc', 'AvgpoolActDesc', 'Interleave2Desc', 'ConvDesc'} <= kinds
+    # conv + eval BN == folded conv + bias
+    blk = spec.blocks[2]
+    f = folding.fold_resnet_block(sd, blk)
+    x = torch.randn(1, blk.width, 6, 6)
+    p = blk.prefix
+    ref = TF.batch_norm(TF.conv2d(x, sd[f'{p}.conv2.weight'], stride=2, padding=1), sd[f'{p}.bn2.running_mean'],
+                        sd[f'{p}.bn2.running_var'], sd[f'{p}.bn2.weight'], sd[f'{p}.bn2.bias'], False, 0.0, 1e-5)
+    wf = f['w2'].view(blk.width, 3, 3, blk.width).permute(0, 3, 1, 2)
+    torch.testing.assert_close(TF.conv2d(x, wf, f['b2'], stride=2, padding=1), ref, rtol=1e-5, atol=1e-5)
