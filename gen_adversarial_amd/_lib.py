@@ -92,7 +92,7 @@ class MaxpoolDesc(C.Structure):
 class ImageIoDesc(C.Structure):
     _fields_ = [('x_nchw', fp), ('noise_nchw', fp), ('noise_coef', fp), ('y_nhwc', fp), ('dy_nhwc', fp),
                 ('dx_nchw', fp), ('N', i32), ('C', i32), ('H', i32), ('W', i32), ('rep', i32), ('backward', i32),
-                ('ld', i32), ('_reserved', i32)]
+                ('ld', i32), ('s2d', i32)]
 
 
 class AxpbyDesc(C.Structure):

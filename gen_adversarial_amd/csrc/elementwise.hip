@@ -503,6 +503,13 @@ __global__ void __launch_bounds__(256) avgpool_act_kernel(const ga_avgpool_act_d
 // ---------------------------------------------------------------------------------------------------------------
 // image boundary: NCHW <-> NHWC, EoT repeat, input noise + clamp (abstract_models.py:129-143; wrappers.py:20)
 // ---------------------------------------------------------------------------------------------------------------
+// offset of pixel p = h*W + w of row n, channel 0, in the NHWC image (plain or space-to-depth)
+__device__ __forceinline__ size_t image_px(const ga_image_io_desc& d, const int ld, const int HW, const int n, const int p) {
+    if (!d.s2d) return ((size_t)n * HW + p) * ld;
+    const int h = p / d.W, w = p - h * d.W;
+    return ((((size_t)n * (d.H >> 1) + (h >> 1)) * (d.W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * ld;
+}
+
 __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d, const long total) {
     const int HW = d.H * d.W;
     const int ld = d.ld > 0 ? d.ld : d.C;
@@ -513,7 +520,7 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
             const int c = (int)(q % d.C); const int n = (int)(q / d.C);
             float v = d.x_nchw[((size_t)(n / d.rep) * d.C + c) * HW + p];
             if (d.noise_nchw) v += d.noise_nchw[i] * d.noise_coef[n];
-            float* o = d.y_nhwc + ((size_t)n * HW + p) * ld;
+            float* o = d.y_nhwc + image_px(d, ld, HW, n, p);
             o[c] = fminf(fmaxf(v, 0.f), 1.f);
             if (c == 0) for (int z = d.C; z < ld; ++z) o[z] = 0.f;      // pad channels of a wider pitch
         }
@@ -528,7 +535,7 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
                 const int n = img * d.rep + r;
                 float v = x;
                 if (d.noise_nchw) v += d.noise_nchw[((size_t)n * d.C + c) * HW + p] * d.noise_coef[n];
-                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[((size_t)n * HW + p) * ld + c];
+                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[image_px(d, ld, HW, n, p) + c];
             }
             d.dx_nchw[i] = acc;
         }
@@ -762,6 +769,7 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
     if (!d->backward && !d->y_nhwc) return GA_E_BADARG;
     if (d->backward && (!d->dy_nhwc || !d->dx_nchw)) return GA_E_BADARG;
     if (d->ld != 0 && d->ld < d->C) return GA_E_BADARG;
+    if (d->s2d && ((d->H | d->W) & 1)) return GA_E_BADARG;
     const long total = (long)d->N * d->C * d->H * d->W;
     hipLaunchKernelGGL(image_io_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();

@@ -42,7 +42,7 @@ class _PreprocessDefense(torch.nn.Module, _EngineOwner):
         self.image_size = x.shape[-1]
         self._run(x, 1, False)
         eng = self._engine(x.shape[0], 1)
-        return eng.acts['x0'].t[..., :3].permute(0, 3, 1, 2).contiguous()      # the NHWC image has a padded channel pitch
+        return eng.input_image_nchw()
 
 
 class GaussianNoiseDefenseModel(_PreprocessDefense):

@@ -164,7 +164,7 @@ class Engine:
     def conv(self, plan, name, x, w, y, *, cin=None, cout=None, bias=None, K=1, sn=1, sd=1, pad=0,
              x2=None, pro_scale=None, pro_shift=None, pro_act=0, pro_per_row=0,
              addend=None, addend_bcast=False, addend2=None, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0,
-             in_hw=None, out_hw=None, n=None, KH=None, KW=None, anchored=False):
+             in_hw=None, out_hw=None, n=None, KH=None, KW=None, anchored=False, explicit_out=False):
         """x, x2, y, addend*, dact_x are torch tensors [N,H,W,C] (or Act.t); shapes are taken from them."""
         d = L.ConvDesc()
         N, Hi, Wi, Cx = x.shape
@@ -194,6 +194,8 @@ class Engine:
         assert w.numel() == d.Cout * d.KH * d.KW * (d.C1 + d.C2), (name, tuple(w.shape), d.Cout, d.KH, d.KW, d.C1, d.C2)
         if anchored:            # sub-pixel kernels: window anchored at the output pixel, taps beyond the border masked
             assert (Ho, Wo) == (Hi, Wi) and pad == 0 and sn == 1 and sd == 1, name
+        elif explicit_out:      # even-sized kernels (asymmetric padding): the output size is given, border taps are masked
+            assert (Ho, Wo) == (Hi, Wi) and sn == 1 and sd == 1, name
         elif sd == 1:
             assert (Hi + 2 * pad - K) // sn + 1 == Ho, (name, Hi, Ho, K, sn, pad)
         else:
@@ -400,17 +402,19 @@ class Engine:
         rep0 = 1 if self.share_encoder else self.rep
         # the NHWC image is kept at a pitch of IMG_LD = 8 channels (3 real + zero pad): the first convolutions then take
         # 16-B loads and the split-bf16 matrix path like every other layer instead of a scalar 3-channel gather
-        x0 = Act(self, R0, H, H, IMG_LD, 'x0')
+        # (a classifier-only ResNet engine takes the image in space-to-depth form: its 7x7/2 stem is then a 4x4/1 conv)
+        self.image_s2d = (not self.has_nvae) and isinstance(self.vspec, ResNetSpec)
+        x0 = Act(self, R0, H // 2, H // 2, 4 * IMG_LD, 'x0') if self.image_s2d else Act(self, R0, H, H, IMG_LD, 'x0')
         io = L.ImageIoDesc()
         io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
-        io.N, io.C, io.H, io.W, io.rep, io.backward, io.ld = R0, 3, H, H, rep0, 0, IMG_LD
+        io.N, io.C, io.H, io.W, io.rep, io.backward, io.ld, io.s2d = R0, 3, H, H, rep0, 0, IMG_LD, int(self.image_s2d)
         self.fwd.add(io, 'image_in')
 
         def bwd_image():
             b = L.ImageIoDesc()
             b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef)
             b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(dx_dst)
-            b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld = R0, 3, H, H, rep0, 1, IMG_LD
+            b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = R0, 3, H, H, rep0, 1, IMG_LD, int(self.image_s2d)
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
@@ -783,11 +787,15 @@ class Engine:
         PRE-activation (ReLU is the consumers' prologue, the identity branch adds relu(sum) through
         GA_CONV_ADDEND_RELU, and its cotangent passes the same relu' as the conv branch, GA_CONV_ADDEND_PRE_DACT)."""
         rs, R = self.vspec, self.rows
-        norm = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
+        if not self.image_s2d:
+            raise NotImplementedError('ResNet behind a purifier: the purified image must be produced in space-to-depth form (next row)')
+        norm = self.devd('norm05_s2d', lambda: {'two': torch.full((4 * IMG_LD,), 2.0), 'mone': torch.full((4 * IMG_LD,), -1.0)})
         two, mone = norm['two'], norm['mone']
         stem = self.devd('resnet.stem', lambda: F.fold_resnet_stem(rsd, IMG_LD))
-        c1 = Act(self, R, img.h // 2, img.w // 2, rs.stem_channels, 'resnet.conv1')
-        self.conv(self.fwd, 'resnet.conv1', img.t, stem['w'], c1.t, bias=stem['b'], K=7, sn=2, pad=3, pro_scale=two, pro_shift=mone)
+        # 7x7/2 pad 3 == 4x4/1 over the space-to-depth image, window anchored two phase-pixels before the output pixel
+        c1 = Act(self, R, img.h, img.w, rs.stem_channels, 'resnet.conv1')
+        self.conv(self.fwd, 'resnet.conv1', img.t, stem['w'], c1.t, bias=stem['b'], K=4, pad=2, explicit_out=True,
+                  pro_scale=two, pro_shift=mone)
         p1 = Act(self, R, c1.h // 2, c1.w // 2, rs.stem_channels, 'resnet.pool')
         m = L.Maxpool3s2Desc()
         m.x, m.y, m.N, m.H, m.W, m.C, m.backward = _ptr(c1.t), _ptr(p1.t), R, c1.h, c1.w, c1.c, 0
@@ -798,7 +806,7 @@ class Engine:
             b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = _ptr(c1.t), _ptr(p1.g), _ptr(c1.g), R, c1.h, c1.w, c1.c, 1
             self.bwd.add(b, 'resnet.maxpool^T')
             c1.g_written = True
-            self.grad_conv('resnet.conv1^T', c1.g, stem['w_bwd'], img, K=7, sn=1, sd=2, pad=3,
+            self.grad_conv('resnet.conv1^T', c1.g, stem['w_bwd'], img, K=4, pad=1, explicit_out=True,
                            dact_x=img.t, dact_scale=two, dact_shift=mone, dact_act=L.GA_ACT_NONE)
         self._bwd_steps.append(bwd_stem)
 
@@ -888,6 +896,15 @@ class Engine:
 
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
+
+    def input_image_nchw(self) -> torch.Tensor:
+        """the pre-processed image of the last forward (after blur / noise / clamp) as [rows, 3, H, W]"""
+        t = self.acts['x0'].t
+        if not self.image_s2d:
+            return t[..., :3].permute(0, 3, 1, 2).contiguous()
+        n, h2, w2, _ = t.shape
+        v = t.view(n, h2, w2, 2, 2, IMG_LD)[..., :3]                     # [n, h/2, w/2, r_h, r_w, c]
+        return v.permute(0, 5, 1, 3, 2, 4).reshape(n, 3, 2 * h2, 2 * w2).contiguous()
 
     # ---- HIP graphs: the ~700-launch plans become one graph launch each (host cost matters at EoT-32 row counts)
     def enable_graphs(self):

@@ -231,8 +231,17 @@ def _conv_bn64(sd: SD, conv: str, bn: str) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def fold_resnet_stem(sd: SD, ld: int) -> dict:
-    w, b = _conv_bn64(sd, 'model.conv1', 'model.bn1')
-    return pad_image_conv({'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(b)}, 3, ld)
+    """7x7 / stride 2 / pad 3 stem as a 4x4 / stride 1 convolution over the space-to-depth image (ga_image_io s2d):
+    out[i] = sum_kh x[2i + kh - 3] w[kh]; with kh' = kh + 1 = 2q + r (a zero tap in front), x[2(i + q - 2) + r] is phase r
+    of the image at position i + q - 2: four taps q with 'pad' 2 per axis, 4*ld input channels ((r_h*2 + r_w)*ld + c)."""
+    w, b = _conv_bn64(sd, 'model.conv1', 'model.bn1')                          # [Cout, 3, 7, 7]
+    co = w.shape[0]
+    w8 = torch.zeros(co, 3, 8, 8, dtype=w.dtype)
+    w8[:, :, 1:, 1:] = w
+    w4 = torch.zeros(co, 2, 2, ld, 4, 4, dtype=w.dtype)                       # [co, r_h, r_w, c, q_h, q_w]
+    w4[:, :, :, :3] = w8.view(co, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4)    # kh' = 2 q_h + r_h, kw' = 2 q_w + r_w
+    w4 = w4.reshape(co, 4 * ld, 4, 4)
+    return {'w': f32(conv_fwd_layout(w4)), 'w_bwd': f32(conv_bwd_layout(w4)), 'b': f32(b)}
 
 
 def fold_resnet_block(sd: SD, blk) -> dict:

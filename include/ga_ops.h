@@ -230,7 +230,9 @@ typedef struct ga_image_io_desc {
     float* dx_nchw;           /* bwd out [N/rep,C,H,W]: sum over the rep rows of each image */
     int N, C, H, W; int rep; int backward;
     int ld;                   /* channel pitch of y_nhwc / dy_nhwc (0 = C); the forward zero-fills channels C..ld-1 */
-    int _reserved;
+    int s2d;                  /* 1: space-to-depth layout — y_nhwc is [N, H/2, W/2, 4*ld], pixel (h, w) channel c at
+                                 [n, h/2, w/2, ((h&1)*2 + (w&1))*ld + c]: a stride-2 conv over the image becomes a stride-1
+                                 conv over this tensor (ResNet's 7x7/2 stem = 4x4 taps x 4*ld channels) */
 } ga_image_io_desc;
 int ga_image_io(const ga_image_io_desc* d, void* stream);
 

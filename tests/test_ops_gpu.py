@@ -603,6 +603,32 @@ def test_image_io():
     close(dx, gx, 1e-6, 'image bwd')
 
 
+def test_image_io_space_to_depth():
+    """s2d layout: pixel (h, w) channel c at [n, h/2, w/2, ((h&1)*2 + (w&1))*ld + c], pad channels zero; backward reads it back"""
+    N, Cc, H, W, ld, rep = 4, 3, 6, 8, 8, 2
+    x = torch.rand(N // rep, Cc, H, W, generator=torch.Generator().manual_seed(1))
+    y = torch.full((N, H // 2, W // 2, 4 * ld), float('nan'), device=DEV)
+    xd = x.to(DEV)
+    d = L.ImageIoDesc()
+    d.x_nchw, d.y_nhwc, d.N, d.C, d.H, d.W, d.rep, d.backward, d.ld, d.s2d = xd.data_ptr(), y.data_ptr(), N, Cc, H, W, rep, 0, ld, 1
+    L.run(d)
+    torch.cuda.synchronize()
+    v = y.cpu().view(N, H // 2, W // 2, 2, 2, ld)
+    assert torch.equal(v[..., Cc:], torch.zeros_like(v[..., Cc:]))
+    img = v[..., :Cc].permute(0, 5, 1, 3, 2, 4).reshape(N, Cc, H, W)
+    assert torch.equal(img, x.repeat_interleave(rep, dim=0))
+    dy = torch.randn(N, H // 2, W // 2, 4 * ld, device=DEV)
+    dx = torch.empty(N // rep, Cc, H, W, device=DEV)
+    b = L.ImageIoDesc()
+    b.x_nchw, b.dy_nhwc, b.dx_nchw, b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = (xd.data_ptr(), dy.data_ptr(), dx.data_ptr(),
+                                                                                           N, Cc, H, W, rep, 1, ld, 1)
+    L.run(b)
+    torch.cuda.synchronize()
+    g_img = dy.cpu().view(N, H // 2, W // 2, 2, 2, ld)[..., :Cc].permute(0, 5, 1, 3, 2, 4).reshape(N, Cc, H, W)
+    ref = g_img.view(N // rep, rep, Cc, H, W).sum(dim=1)
+    close(dx.cpu(), ref, 1e-6, 's2d image backward')
+
+
 @pytest.mark.parametrize('H,k', [(64, 15), (32, 7), (16, 3), (20, 9)])
 def test_gauss_blur_forward_and_adjoint(H, k):
     from oracle import defender_oracle as D

@@ -79,3 +79,28 @@ def test_gender_classifier_api(tmp_path):
     assert model.get_purified(x) is x
     with pytest.raises(NotImplementedError):
         load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=1, device=DEV))
+
+
+def test_gender_ablation_defenders_see_the_preprocessed_image(tmp_path):
+    """defense_type 'ablation' on the ResNet classifier: the pre-processed image (space-to-depth inside the engine) comes
+    back as a plain NCHW image; blur matches the oracle's kornia restatement"""
+    from argparse import Namespace
+    import yaml
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    blocks, wd = (1, 1, 1, 1), 8
+    sd = init_resnet_state_dict(2, wd, 5, blocks)
+    torch.save({'state_dict': sd}, tmp_path / 'resnet.pt')
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(2))
+    for kind in ('blur', 'noise'):
+        with open(tmp_path / f'{kind}.yaml', 'w') as f:
+            yaml.safe_dump({'classifier_path': str(tmp_path / 'resnet.pt'), 'type': kind}, f)
+        _, m = load(Namespace(config=str(tmp_path / f'{kind}.yaml'), experiment='gender', defense_type='ablation', eot_steps=2, device=DEV))
+        p = m.get_purified(x.to(DEV))
+        assert p.shape == x.shape and 0 <= p.min().item() and p.max().item() <= 1
+        if kind == 'blur':
+            assert (p.cpu() - D.apply_gaussian_blur(x)).abs().max().item() < 1e-5
+            ref = D.resnet_classifier_call(sd, build_resnet_spec(2, wd, blocks), D.apply_gaussian_blur(x))
+            assert (m.model(x.to(DEV)).cpu() - ref).abs().max().item() < 1e-3
+        else:
+            assert abs((p.cpu() - x).flatten(1).norm(dim=1).max().item() - 4.0) < 0.4      # L2 = eps (4.0 for gender) before the clamp
