@@ -463,6 +463,52 @@ __global__ void __launch_bounds__(256) maxpool3s2_kernel(const ga_maxpool3s2_des
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// grouped convolution, few channels per group (ResNeXt conv2 and the sub-kernels of its transposes): one thread per
+// output pixel x output-channel quad; the quads of a group read the same input channels (L1 broadcast), weights from L1/L2
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gconv_kernel(const ga_gconv_desc d, const long total4) {
+    const int C4 = d.C / 4, K = d.KH * d.KW * d.cg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4); long p = i / C4;
+        const int wo = (int)(p % d.Wo); p /= d.Wo;
+        const int ho = (int)(p % d.Ho); const int n = (int)(p / d.Ho);
+        const int co = 4 * q, g0 = (co / d.cg) * d.cg;                  // first input channel of this quad's group
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (d.bias) acc = ld4(d.bias + co);
+        const float* wrow = d.w + (size_t)co * K;
+        for (int kh = 0; kh < d.KH; ++kh) {
+            const int h = ho * d.stride - d.pad + kh;
+            if (h < 0 || h >= d.Hi) continue;
+            for (int kw = 0; kw < d.KW; ++kw) {
+                const int w = wo * d.stride - d.pad + kw;
+                if (w < 0 || w >= d.Wi) continue;
+                const float* xp = d.x + (((size_t)n * d.Hi + h) * d.Wi + w) * d.C + g0;
+                const float* wp = wrow + (kh * d.KW + kw) * d.cg;
+                for (int c = 0; c < d.cg; c += 4) {
+                    floatx4 v = ld4(xp + c);
+                    if (d.pro_act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const floatx4 w4 = ld4(wp + (size_t)o * K + c);
+                        acc[o] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+                    }
+                }
+            }
+        }
+        const size_t o = (((size_t)n * d.Ho + ho) * d.Wo + wo) * d.C + co;
+        if (d.dact_x) {
+            const floatx4 u = ld4(d.dact_x + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= act_bwd_fast(u[e], d.dact_act);
+        }
+        *reinterpret_cast<floatx4*>(d.y + o) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // global average pool with an activation prologue (torchvision ResNet avgpool after the last ReLU)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) avgpool_act_kernel(const ga_avgpool_act_desc d, const int nchunks) {
@@ -748,6 +794,18 @@ extern "C" int ga_maxpool3s2(const ga_maxpool3s2_desc* d, void* s) {
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
     const long total4 = d->backward ? (long)d->N * d->H * d->W * (d->C / 4) : (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
     hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_gconv(const ga_gconv_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || !d->w || !d->y || d->N <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0) return GA_E_BADARG;
+    if (d->C <= 0 || d->cg <= 0 || d->C % d->cg || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0) return GA_E_BADARG;
+    if (d->cg % 4) return GA_E_UNSUPPORTED;
+    if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->y) || (d->bias && !aligned16(d->bias)) ||
+        (d->dact_x && !aligned16(d->dact_x))) return GA_E_ALIGN;
+    const long total4 = (long)d->N * d->Ho * d->Wo * (d->C / 4);
+    hipLaunchKernelGGL(gconv_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }
 

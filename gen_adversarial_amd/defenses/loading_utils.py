@@ -7,7 +7,7 @@ holders instead of nn.Modules: the arithmetic lives in libga_ops, not in torch m
                                             projector head model.fc.{0,1,3}.* (loading_utils.py:10-16)
   load_NVAE(path, device, temperature)      ckpt['configuration'] {'autoencoder': cfg, 'resolution': (C,H,W)} and
                                             ckpt[f'state_dict_temp={temperature}']
-E4E / Style-Transformer / ResNeXt loaders are the "next" rows of SURVEY.md §8 and raise NotImplementedError.
+E4E / Style-Transformer loaders are the "next" rows of SURVEY.md §8 and raise NotImplementedError.
 """
 from __future__ import annotations
 
@@ -44,10 +44,12 @@ class ResNetWeights:
     n_classes: int
     width_div: int = 1
     blocks: Tuple[int, ...] = RESNET50_BLOCKS
+    groups: int = 1
+    width_per_group: int = 64
 
     @property
     def spec(self):
-        return build_resnet_spec(self.n_classes, self.width_div, self.blocks)
+        return build_resnet_spec(self.n_classes, self.width_div, self.blocks, self.groups, self.width_per_group)
 
     def to(self, device):
         return self
@@ -108,6 +110,16 @@ def load_ResNet50(path: str, device: str, n_classes: int = 2) -> ResNetWeights:
     return ResNetWeights(sd, sd['model.fc.3.weight'].shape[0] if n_classes is None else n_classes, width_div, blocks)
 
 
-load_ResNext50 = _next('load_ResNext50')
+def load_ResNext50(path: str, device: str, n_classes: int = 4) -> ResNetWeights:
+    """src/defenses/loading_utils.py:28-34: resnext50_32x4d (groups 32, 4 channels per group at the first stage)."""
+    sd = _torch_load(path)['state_dict']
+    width_div = 64 // sd['model.conv1.weight'].shape[0]
+    blocks = tuple(1 + max(int(k.split('.')[2]) for k in sd if k.startswith(f'model.layer{i}.')) for i in (1, 2, 3, 4))
+    w2 = sd['model.layer1.0.conv2.weight']
+    groups = w2.shape[0] // w2.shape[1]
+    return ResNetWeights(sd, sd['model.fc.3.weight'].shape[0] if n_classes is None else n_classes, width_div, blocks, groups,
+                         width_per_group=w2.shape[1] * width_div)
+
+
 load_E4EStyleGan = _next('load_E4EStyleGan')
 load_TranStyleGan = _next('load_TranStyleGan')

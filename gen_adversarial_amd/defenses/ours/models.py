@@ -8,7 +8,7 @@ from __future__ import annotations
 import torch
 
 from ...engine import Engine
-from ..loading_utils import load_NVAE, load_ResNet50, load_Vgg11, NVAEWeights
+from ..loading_utils import load_NVAE, load_ResNet50, load_ResNext50, load_Vgg11, NVAEWeights
 from .abstract_models import BaseClassificationModel, MLVGMDefenseModel
 
 
@@ -33,6 +33,18 @@ class CelebaGenderClassifier(BaseClassificationModel, torch.nn.Module):
 
     def load_classifier(self, model_path: str, device: str):
         return load_ResNet50(model_path, device)
+
+
+class CarsTypeClassifier(BaseClassificationModel, torch.nn.Module):
+    """Stanford-Cars 128 type classifier, ResNeXt-50 32x4d (models.py:59-77)."""
+
+    def __init__(self, model_path: str, device: str):
+        torch.nn.Module.__init__(self)
+        self.image_size = 128
+        BaseClassificationModel.__init__(self, model_path, device, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+
+    def load_classifier(self, model_path: str, device: str):
+        return load_ResNext50(model_path, device)
 
 
 class NVAEDefenseModel(MLVGMDefenseModel, torch.nn.Module):
@@ -66,6 +78,5 @@ def _next(name, what):
     return _NotBuilt
 
 
-CarsTypeClassifier = _next('CarsTypeClassifier', 'ResNeXt-50 classifier (models.py:59-77)')
 E4EStyleGanDefenseModel = _next('E4EStyleGanDefenseModel', 'e4e + StyleGAN2 purifier (models.py:80-132)')
 TransStyleGanDefenseModel = _next('TransStyleGanDefenseModel', 'Style-Transformer purifier (models.py:277-353)')

@@ -215,10 +215,23 @@ class Engine:
         target.g_written = True
         return d
 
-    def grad_conv_up2(self, name, x, wts, key, target: Act, *, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0):
+    def gconv(self, plan, name, x, w, y, cg, *, KH=3, KW=3, stride=1, pad=1, bias=None, pro_act=0, dact_x=None, dact_act=0):
+        """grouped convolution with cg channels per group (ga_gconv): x, y NHWC tensors, w [C][KH*KW*cg]"""
+        d = L.GconvDesc()
+        n, hi, wi, c = x.shape
+        _, ho, wo, cy = y.shape
+        assert cy == c and c % cg == 0 and w.numel() == c * KH * KW * cg, (name, tuple(x.shape), tuple(y.shape), tuple(w.shape), cg)
+        d.x, d.w, d.bias, d.dact_x, d.y = _ptr(x), _ptr(w), _ptr(bias), _ptr(dact_x), _ptr(y)
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.C, d.cg = n, hi, wi, ho, wo, c, cg
+        d.KH, d.KW, d.stride, d.pad, d.pro_act, d.dact_act = KH, KW, stride, pad, pro_act, dact_act
+        plan.add(d, name)
+        return d
+
+    def grad_conv_up2(self, name, x, wts, key, target: Act, *, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0, cg=0):
         """Backward-to-input of a stride-2 conv into target.g (twice the resolution of x) by sub-pixel decomposition:
         one stride-1 ga_conv2d per output parity that meets a tap (folding.subpixel_weights) into dense scratch planes,
-        then ga_interleave2, which carries the epilogue (act', accumulation into an already written gradient)."""
+        then ga_interleave2, which carries the epilogue (act', accumulation into an already written gradient).
+        cg > 0: the conv is grouped with cg channels per group (ga_gconv, folding.grouped_subpixel_weights)."""
         n, h, w, _ = x.shape
         il = L.Interleave2Desc()
         for a in (0, 1):
@@ -226,10 +239,13 @@ class Engine:
                 wm = wts.get(f'{key}{a}{b}')
                 if wm is None:
                     continue
-                taps = wm.shape[1] // x.shape[3]                    # 1, 2 or 4 taps: 1x1, 2x1 / 1x2, 2x2 windows
+                taps = wm.shape[1] // (cg or x.shape[3])            # 1, 2 or 4 taps: 1x1, 2x1 / 1x2, 2x2 windows
                 kh, kw = 1 + (a if taps >= 2 else 0), 1 + (b if taps >= 2 else 0)
                 plane = self.scratch((n, h, w, target.c), f'subpix{a}{b}')
-                self.conv(self.bwd, f'{name}[{a}{b}]', x, wm, plane, KH=kh, KW=kw, pad=0, anchored=True)
+                if cg:
+                    self.gconv(self.bwd, f'{name}[{a}{b}]', x, wm, plane, cg, KH=kh, KW=kw, stride=1, pad=0)
+                else:
+                    self.conv(self.bwd, f'{name}[{a}{b}]', x, wm, plane, KH=kh, KW=kw, pad=0, anchored=True)
                 il.s[2 * a + b] = _ptr(plane)
         il.y, il.N, il.H, il.W, il.C = _ptr(target.g), n, 2 * h, 2 * w, target.c
         il.dact_x, il.dact_scale, il.dact_shift, il.dact_act = _ptr(dact_x), _ptr(dact_scale), _ptr(dact_shift), dact_act
@@ -848,7 +864,11 @@ class Engine:
         t2 = Act(self, R, h // st, w // st, blk.width, p + '.t2')
         s_out = Act(self, R, h // st, w // st, blk.cout, p + '.sum')
         self.conv(self.fwd, p + '.conv1', s_in.t, wts['w1'], t1.t, bias=wts['b1'], K=1, pro_act=L.GA_ACT_RELU)
-        self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, sn=st, pad=1, pro_act=L.GA_ACT_RELU)
+        cg = blk.width // blk.groups if blk.groups > 1 else 0                      # ResNeXt: grouped 3x3
+        if cg:
+            self.gconv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, cg, stride=st, pad=1, bias=wts['b2'], pro_act=L.GA_ACT_RELU)
+        else:
+            self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, sn=st, pad=1, pro_act=L.GA_ACT_RELU)
         if blk.downsample:
             ds = Act(self, R, h // st, w // st, blk.cout, p + '.shortcut')
             self.conv(self.fwd, p + '.downsample', s_in.t, wts['wd'], ds.t, bias=wts['bd'], K=1, sn=st, pad=0, pro_act=L.GA_ACT_RELU)
@@ -859,10 +879,14 @@ class Engine:
 
         def backward():
             self.grad_conv(p + '.conv3^T', s_out.g, wts['w3_bwd'], t2, K=1, dact_x=t2.t, dact_act=L.GA_ACT_RELU)
-            if st == 1:
+            if st == 1 and cg:
+                assert not t1.g_written
+                self.gconv(self.bwd, p + '.conv2^T', t2.g, wts['w2_bwd'], t1.g, cg, stride=1, pad=1, dact_x=t1.t, dact_act=L.GA_ACT_RELU)
+                t1.g_written = True
+            elif st == 1:
                 self.grad_conv(p + '.conv2^T', t2.g, wts['w2_bwd'], t1, K=3, pad=1, dact_x=t1.t, dact_act=L.GA_ACT_RELU)
             else:
-                self.grad_conv_up2(p + '.conv2^T', t2.g, wts, 'w2_sub', t1, dact_x=t1.t, dact_act=L.GA_ACT_RELU)
+                self.grad_conv_up2(p + '.conv2^T', t2.g, wts, 'w2_sub', t1, dact_x=t1.t, dact_act=L.GA_ACT_RELU, cg=cg)
             if blk.downsample:
                 self.grad_conv(p + '.conv1^T', t1.g, wts['w1_bwd'], s_in, K=1, dact_x=s_in.t, dact_act=L.GA_ACT_RELU)
                 if st == 1:

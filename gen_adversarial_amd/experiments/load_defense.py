@@ -5,7 +5,8 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `args.attacks` and attaches `defense_model.get_purified`.
 
 Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only), 'ablation' (noise / blur) and 'ours'
-(NVAE purifier); experiment 'gender' (ResNet-50 on 256x256) with 'base' | 'trades' | 'ablation'; the reference's
+(NVAE purifier); experiments 'gender' (ResNet-50, 256x256) and 'cars' (ResNeXt-50, 128x128) with 'base' | 'trades' |
+'ablation'; the reference's
 attack sets (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
 Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
 """
@@ -16,7 +17,8 @@ import yaml
 from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
 from ..defenses.ablations.models import GaussianBlurDefenseModel, GaussianNoiseDefenseModel
-from ..defenses.ours.models import CelebaGenderClassifier, CelebaIdentityClassifier, E4EStyleGanDefenseModel, NVAEDefenseModel
+from ..defenses.ours.models import (CarsTypeClassifier, CelebaGenderClassifier, CelebaIdentityClassifier,
+                                   E4EStyleGanDefenseModel, NVAEDefenseModel, TransStyleGanDefenseModel)
 from ..defenses.wrappers import EoTWrapper
 
 
@@ -50,7 +52,16 @@ def load(args: Namespace):
         base_classifier = CelebaGenderClassifier(d_params.classifier_path, args.device)
         hl_instance = E4EStyleGanDefenseModel
     elif args.experiment == 'cars':
-        raise NotImplementedError("experiment 'cars' (ResNeXt-50 + Style-Transformer) is a next row, not built yet")
+        # ResNeXt-50 classifier (load_defense.py:59-73): base / trades / ablation; the Style-Transformer purifier is a next row
+        args.image_size = 128
+        args.attacks = {
+            'deepfool': DeepFool(num_classes=4, overshoot=0.02, max_iter=256),
+            'c&w': CW(c=24., kappa=0.02, steps=1024, lr=2e-3, n_restarts=8),
+            'autoattack': AutoAttack()
+        }
+        args.pgd = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)
+        base_classifier = CarsTypeClassifier(d_params.classifier_path, args.device)
+        hl_instance = TransStyleGanDefenseModel
     else:
         raise NotImplementedError
 

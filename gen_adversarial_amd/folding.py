@@ -244,15 +244,35 @@ def fold_resnet_stem(sd: SD, ld: int) -> dict:
     return {'w': f32(conv_fwd_layout(w4)), 'w_bwd': f32(conv_bwd_layout(w4)), 'b': f32(b)}
 
 
+def grouped_bwd_weights(w: torch.Tensor, groups: int) -> torch.Tensor:
+    """[C, cg, k, k] grouped forward weights -> the grouped weights of the backward-to-input conv, same shape: within each
+    group input and output channels swap, the kernel flips spatially."""
+    c, cg, k, _ = w.shape
+    return w.view(groups, c // groups, cg, k, k).transpose(1, 2).flip(3, 4).reshape(c, cg, k, k).contiguous()
+
+
+def grouped_subpixel_weights(w: torch.Tensor, groups: int) -> dict:
+    """subpixel_weights per group, stacked: {(a, b): ([C][taps*cg] in ga_gconv layout, KH, KW)}"""
+    c, cg, k, _ = w.shape
+    per = [subpixel_weights(w[g * cg:(g + 1) * cg]) for g in range(groups)]        # each: [cg_in][taps*cg_out]
+    return {ab: (torch.cat([p[ab][0] for p in per], dim=0).contiguous(), per[0][ab][1], per[0][ab][2]) for ab in per[0]}
+
+
 def fold_resnet_block(sd: SD, blk) -> dict:
     p = blk.prefix
     w1, b1 = _conv_bn64(sd, f'{p}.conv1', f'{p}.bn1')
     w2, b2 = _conv_bn64(sd, f'{p}.conv2', f'{p}.bn2')
     w3, b3 = _conv_bn64(sd, f'{p}.conv3', f'{p}.bn3')
     out = {'w1': f32(conv_fwd_layout(w1)), 'w1_bwd': f32(conv_bwd_layout(w1)), 'b1': f32(b1),
-           'w2': f32(conv_fwd_layout(w2)), 'b2': f32(b2),
+           'w2': f32(conv_fwd_layout(w2)), 'b2': f32(b2),          # grouped: [C][9*cg], the ga_gconv layout
            'w3': f32(conv_fwd_layout(w3)), 'w3_bwd': f32(conv_bwd_layout(w3)), 'b3': f32(b3)}
-    if blk.stride == 1:
+    if blk.groups > 1:
+        if blk.stride == 1:
+            out['w2_bwd'] = f32(conv_fwd_layout(grouped_bwd_weights(w2, blk.groups)))
+        else:
+            for (a, b), (wm, kh, kw) in grouped_subpixel_weights(w2, blk.groups).items():
+                out[f'w2_sub{a}{b}'] = wm
+    elif blk.stride == 1:
         out['w2_bwd'] = f32(conv_bwd_layout(w2))
     else:
         for (a, b), (wm, kh, kw) in subpixel_weights(w2).items():

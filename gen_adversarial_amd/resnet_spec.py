@@ -12,6 +12,10 @@ stages of [3, 4, 6, 3] Bottlenecks with widths 64/128/256/512 and expansion 4 (1
 after each, ReLU after the first two and after the residual sum; a 1x1 strided conv + BN on the shortcut where shapes
 change), AdaptiveAvgPool2d((1,1)), all convolutions without bias.
 
+ResNeXt-50 32x4d (src/classifier/model.py:52-70, `CarsTypeClassifier`) is the same network with `groups=32,
+width_per_group=4`: the Bottleneck width becomes planes * 4/64 * 32 (128/256/512/1024) and its 3x3 convolution is
+grouped (weight [width, width/32, 3, 3]).
+
 `width_div` shrinks every channel count and `blocks` the stage depths (tests only); the real model is the default.
 """
 from __future__ import annotations
@@ -36,6 +40,7 @@ class BottleneckSpec:
     cout: int
     stride: int
     downsample: bool
+    groups: int = 1
 
 
 @dataclass
@@ -46,16 +51,17 @@ class ResNetSpec:
     n_classes: int
 
 
-def build_resnet_spec(n_classes: int = 2, width_div: int = 1, blocks: Tuple[int, ...] = RESNET50_BLOCKS) -> ResNetSpec:
+def build_resnet_spec(n_classes: int = 2, width_div: int = 1, blocks: Tuple[int, ...] = RESNET50_BLOCKS, groups: int = 1,
+                      width_per_group: int = 64) -> ResNetSpec:
     stem = 64 // width_div
     out: List[BottleneckSpec] = []
     cin = stem
     for li, (nb, planes) in enumerate(zip(blocks, (64, 128, 256, 512))):
-        width = planes // width_div
+        width = int(planes * (width_per_group / 64.0)) * groups // width_div      # torchvision Bottleneck.__init__
+        cout = planes * 4 // width_div
         for b in range(nb):
             stride = 2 if (b == 0 and li > 0) else 1
-            cout = width * 4
-            out.append(BottleneckSpec(f'model.layer{li + 1}.{b}', cin, width, cout, stride, b == 0 and (stride != 1 or cin != cout)))
+            out.append(BottleneckSpec(f'model.layer{li + 1}.{b}', cin, width, cout, stride, b == 0 and (stride != 1 or cin != cout), groups))
             cin = cout
     return ResNetSpec(stem, out, cin, n_classes)
 
@@ -68,9 +74,10 @@ def _bn(sd, rng, prefix, c):
     sd[f'{prefix}.num_batches_tracked'] = torch.tensor(0, dtype=torch.long)
 
 
-def init_resnet_state_dict(n_classes: int = 2, width_div: int = 1, seed: int = 0, blocks: Tuple[int, ...] = RESNET50_BLOCKS):
+def init_resnet_state_dict(n_classes: int = 2, width_div: int = 1, seed: int = 0, blocks: Tuple[int, ...] = RESNET50_BLOCKS,
+                           groups: int = 1, width_per_group: int = 64):
     """seeded random weights with torchvision's key names and shapes (He-style scales so that activations stay O(1))"""
-    spec = build_resnet_spec(n_classes, width_div, blocks)
+    spec = build_resnet_spec(n_classes, width_div, blocks, groups, width_per_group)
     rng = _Rng(seed)
     sd = OrderedDict()
     sd['model.conv1.weight'] = rng.normal((spec.stem_channels, 3, 7, 7), std=np.sqrt(2.0 / (3 * 49)))
@@ -78,7 +85,8 @@ def init_resnet_state_dict(n_classes: int = 2, width_div: int = 1, seed: int = 0
     for b in spec.blocks:
         sd[f'{b.prefix}.conv1.weight'] = rng.normal((b.width, b.cin, 1, 1), std=np.sqrt(2.0 / b.cin))
         _bn(sd, rng, f'{b.prefix}.bn1', b.width)
-        sd[f'{b.prefix}.conv2.weight'] = rng.normal((b.width, b.width, 3, 3), std=np.sqrt(2.0 / (b.width * 9)))
+        cg = b.width // b.groups
+        sd[f'{b.prefix}.conv2.weight'] = rng.normal((b.width, cg, 3, 3), std=np.sqrt(2.0 / (cg * 9)))
         _bn(sd, rng, f'{b.prefix}.bn2', b.width)
         sd[f'{b.prefix}.conv3.weight'] = rng.normal((b.cout, b.width, 1, 1), std=0.5 * np.sqrt(2.0 / b.width))
         _bn(sd, rng, f'{b.prefix}.bn3', b.cout)

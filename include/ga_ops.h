@@ -202,6 +202,22 @@ typedef struct ga_maxpool2_desc {
 } ga_maxpool2_desc;
 int ga_maxpool2(const ga_maxpool2_desc* d, void* stream);
 
+/* Grouped convolution with few channels per group (torchvision ResNeXt Bottleneck `conv2`: 3x3, groups = 32, 4..32
+ * channels per group; classifier/model.py:52-70) and the small kernels of its backward-to-input pass.  HBM-bound,
+ * vector ALU only.  x: [N,Hi,Wi,C], y: [N,Ho,Wo,C], C = groups * cg, cg % 4 == 0; w: [C][KH*KW*cg] with
+ * k = (kh*KW + kw)*cg + ci_local (the rows of group g read input channels g*cg .. g*cg+cg-1).
+ *   y[n,ho,wo,co] = bias[co] + sum_{kh,kw,ci} act(x[n, ho*stride - pad + kh, wo*stride - pad + kw, g*cg + ci]) * w[co][...]
+ *   then y *= act'(dact_x) when dact_x is given (backward use).  Taps outside the image are skipped (zero padding), so
+ *   windows anchored at the output pixel (pad 0, Ho = Hi) work as for ga_conv2d. */
+typedef struct ga_gconv_desc {
+    const float* x; const float* w; const float* bias; const float* dact_x; float* y;
+    int N, Hi, Wi, Ho, Wo, C, cg;
+    int KH, KW, stride, pad;
+    int pro_act, dact_act;
+    int _reserved;
+} ga_gconv_desc;
+int ga_gconv(const ga_gconv_desc* d, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pool (torchvision ResNet stem, resnet.py `self.maxpool`), on pre-activation maps (ReLU
  * commutes with max).  x: [N,H,W,C], y: [N,H/2,W/2,C] (H, W even).  backward: dx[p] = sum of dy over the windows whose
  * first maximal element in scan order is p (aten::max_pool2d_with_indices keeps the first), gathered per input pixel:
@@ -281,7 +297,7 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
-                  GA_OP_AVGPOOL_ACT = 16 };
+                  GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -291,7 +307,7 @@ typedef struct ga_op {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
-        ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap;
+        ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

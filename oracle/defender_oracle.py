@@ -50,8 +50,8 @@ def vgg_forward(sd: SD, spec: VggSpec, x: torch.Tensor) -> torch.Tensor:
 
 
 def resnet_forward(sd: SD, spec, x: torch.Tensor) -> torch.Tensor:
-    """ResNet.forward — src/classifier/model.py:10-28: torchvision resnet50 (published definition, see
-    gen_adversarial_amd/resnet_spec.py) with the projector head of :19-24, eval mode."""
+    """ResNet.forward / ResNext.forward — src/classifier/model.py:10-28, 52-70: torchvision resnet50 / resnext50_32x4d
+    (published definition, see gen_adversarial_amd/resnet_spec.py) with the projector head of :19-24, eval mode."""
     def bn(p, t):
         return F.batch_norm(t, sd[f'{p}.running_mean'], sd[f'{p}.running_var'], sd[f'{p}.weight'], sd[f'{p}.bias'],
                             False, 0.0, 1e-5)
@@ -60,7 +60,7 @@ def resnet_forward(sd: SD, spec, x: torch.Tensor) -> torch.Tensor:
     for b in spec.blocks:
         p = b.prefix
         o = F.relu(bn(f'{p}.bn1', F.conv2d(x, sd[f'{p}.conv1.weight'])))
-        o = F.relu(bn(f'{p}.bn2', F.conv2d(o, sd[f'{p}.conv2.weight'], stride=b.stride, padding=1)))
+        o = F.relu(bn(f'{p}.bn2', F.conv2d(o, sd[f'{p}.conv2.weight'], stride=b.stride, padding=1, groups=b.groups)))
         o = bn(f'{p}.bn3', F.conv2d(o, sd[f'{p}.conv3.weight']))
         idt = bn(f'{p}.downsample.1', F.conv2d(x, sd[f'{p}.downsample.0.weight'], stride=b.stride)) if b.downsample else x
         x = F.relu(o + idt)

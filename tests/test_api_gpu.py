@@ -172,7 +172,7 @@ def test_base_classifier_path(setup, tmp_path):
     assert (diff.norm() / gr.norm()).item() < 2e-2          # max-pool near-ties: see test_engine_gpu
     assert clf.get_purified(x) is x
     with pytest.raises(NotImplementedError):
-        load(Namespace(config=args.config, experiment='cars', defense_type='ours', eot_steps=1, device=DEV))
+        load(Namespace(config=args.config, experiment='imagenet', defense_type='ours', eot_steps=1, device=DEV))
 
 
 def test_ablation_defenders_and_alpha_objective(setup, tmp_path):

@@ -603,6 +603,40 @@ def test_image_io():
     close(dx, gx, 1e-6, 'image bwd')
 
 
+@pytest.mark.parametrize('stride,cg,act', [(1, 4, 3), (2, 8, 3), (1, 16, 0)])
+def test_gconv(stride, cg, act):
+    """grouped conv (ResNeXt conv2) forward with ReLU prologue, and as its own backward-to-input (stride 1) with act'"""
+    from gen_adversarial_amd.folding import conv_fwd_layout, grouped_bwd_weights
+    N, G, H = 2, 3, 8
+    Cc = G * cg
+    x = g(N, Cc, H, H, seed=1)
+    w = g(Cc, cg, 3, 3, seed=2, scale=1.0 / np.sqrt(cg * 9))
+    b = g(Cc, seed=3)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(ACTS[act](xr), w, b, stride=stride, padding=1, groups=G)
+    Ho = H // stride
+    y = torch.full((N, Ho, Ho, Cc), float('nan'), device=DEV)
+    xd, wd, bd = nhwc(x), conv_fwd_layout(w).to(DEV), b.to(DEV)
+    d = L.GconvDesc()
+    d.x, d.w, d.bias, d.y = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr()
+    d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.C, d.cg, d.KH, d.KW, d.stride, d.pad, d.pro_act = N, H, H, Ho, Ho, Cc, cg, 3, 3, stride, 1, act
+    L.run(d)
+    torch.cuda.synchronize()
+    close(nchw(y), ref, 2e-5, 'gconv fwd')
+    if stride == 1:
+        cot = g(*ref.shape, seed=4)
+        (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+        wb = conv_fwd_layout(grouped_bwd_weights(w, G)).to(DEV)
+        dy, dx = nhwc(cot), torch.full((N, H, H, Cc), float('nan'), device=DEV)
+        bdesc = L.GconvDesc()
+        bdesc.x, bdesc.w, bdesc.y, bdesc.dact_x = dy.data_ptr(), wb.data_ptr(), dx.data_ptr(), xd.data_ptr()
+        bdesc.N, bdesc.Hi, bdesc.Wi, bdesc.Ho, bdesc.Wo, bdesc.C, bdesc.cg = N, H, H, H, H, Cc, cg
+        bdesc.KH, bdesc.KW, bdesc.stride, bdesc.pad, bdesc.dact_act = 3, 3, 1, 1, act
+        L.run(bdesc)
+        torch.cuda.synchronize()
+        close(nchw(dx), gx, 2e-5, 'gconv bwd')
+
+
 def test_image_io_space_to_depth():
     """s2d layout: pixel (h, w) channel c at [n, h/2, w/2, ((h&1)*2 + (w&1))*ld + c], pad channels zero; backward reads it back"""
     N, Cc, H, W, ld, rep = 4, 3, 6, 8, 8, 2

@@ -21,10 +21,10 @@ from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state
 DEV = 'cuda:0'
 
 
-def _check(width_div, blocks, res, rows, precision, tol):
+def _check(width_div, blocks, res, rows, precision, tol, groups=1, wpg=64, n_classes=2):
     from oracle import defender_oracle as D
-    spec = build_resnet_spec(2, width_div, blocks)
-    sd = init_resnet_state_dict(2, width_div, 7, blocks)
+    spec = build_resnet_spec(n_classes, width_div, blocks, groups, wpg)
+    sd = init_resnet_state_dict(n_classes, width_div, 7, blocks, groups, wpg)
     gen = torch.Generator().manual_seed(3)
     x = torch.rand(rows, 3, res, res, generator=gen)
     xr = x.clone().requires_grad_(True)
@@ -40,7 +40,7 @@ def _check(width_div, blocks, res, rows, precision, tol):
     eng.backward()
     diff = (eng.dx.cpu() - gx).double()
     rel = (diff.norm() / gx.double().norm()).item()
-    print(f'resnet wd{width_div} {blocks} {res}px [{precision}]: logits err {e_l:.2e} (|logits| {logits.abs().max().item():.2f}) '
+    print(f'resnet wd{width_div} {blocks} g{groups} {res}px [{precision}]: logits err {e_l:.2e} (|logits| {logits.abs().max().item():.2f}) '
           f'grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
     assert e_l < tol
     assert rel < 2e-2            # the stem's max pool and the ReLUs make the gradient discontinuous at near-ties
@@ -53,6 +53,38 @@ def test_reduced_resnet_matches_oracle(precision, tol):
 
 def test_full_resnet50_matches_oracle():
     _check(1, (3, 4, 6, 3), 256, 2, 'bf16x3', 1e-3)
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])
+def test_reduced_resnext_matches_oracle(precision, tol):
+    """grouped 3x3 convs (ga_gconv), stride 1 and 2, and their grouped transposes"""
+    _check(2, (2, 2, 1, 1), 64, 3, precision, tol, groups=4, wpg=16, n_classes=4)
+
+
+def test_full_resnext50_matches_oracle():
+    """resnext50_32x4d at the cars resolution (128x128)"""
+    _check(1, (3, 4, 6, 3), 128, 2, 'bf16x3', 1e-3, groups=32, wpg=4, n_classes=4)
+
+
+def test_cars_classifier_api(tmp_path):
+    from argparse import Namespace
+    import yaml
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    blocks, wd, groups, wpg = (1, 1, 1, 1), 2, 4, 16
+    sd = init_resnet_state_dict(4, wd, 5, blocks, groups, wpg)
+    torch.save({'state_dict': sd}, tmp_path / 'resnext.pt')
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(tmp_path / 'resnext.pt')}, f)
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='cars', defense_type='base', eot_steps=1, device=DEV))
+    assert args.image_size == 128 and model.classifier.groups == groups and model.classifier.width_per_group == wpg
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    ref = D.resnet_classifier_call(sd, build_resnet_spec(4, wd, blocks, groups, wpg), x)
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    assert (out.detach().cpu() - ref).abs().max().item() < 1e-3
+    (g,) = torch.autograd.grad(out[:, 2].sum(), [xd])
+    assert torch.isfinite(g).all() and g.abs().max().item() > 0
 
 
 def test_gender_classifier_api(tmp_path):
