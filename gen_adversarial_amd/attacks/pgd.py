@@ -12,6 +12,8 @@ import torch
 
 
 class PGDLinf:
+    batched = True      # `image` may hold several images: each is attacked independently (see test_defense.evaluate_shard)
+
     def __init__(self, eps: float = 8.0 / 255.0, step_size: float = 2.0 / 255.0, steps: int = 40,
                  random_start: bool = False):
         self.eps, self.step_size, self.steps, self.random_start = eps, step_size, steps, random_start

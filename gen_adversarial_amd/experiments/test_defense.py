@@ -44,10 +44,33 @@ def seed_everything(seed: int = 42):
         torch.cuda.manual_seed_all(seed)
 
 
-def evaluate_shard(defense_model, attacks: Dict[str, Callable], images: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+def evaluate_shard(defense_model, attacks: Dict[str, Callable], images: torch.Tensor, labels: torch.Tensor,
+                   batch_images: int = 1) -> torch.Tensor:
     """per image: [clean correct (0/1), distortion per attack] — the loop of test_defense.py:123-200, one image at a time
-    exactly as the reference drives its attacks."""
+    exactly as the reference drives its attacks.  batch_images > 1: the clean pass and every attack that declares
+    `batched = True` (PGD-Linf: images are attacked independently, per-image early stop) take `batch_images` images per
+    call, i.e. batch_images x EoT defender rows per plan run — the MI355X is launch-bound on one image x EoT 32; the
+    reference's single-image attacks keep their one-image protocol."""
     out = torch.zeros(images.shape[0], 1 + len(attacks))
+    if batch_images > 1:
+        per_image = {j: a for j, a in enumerate(attacks.values()) if not getattr(a, 'batched', False)}
+        for lo in range(0, images.shape[0], batch_images):
+            x = images[lo:lo + batch_images].clamp(0.0, 1.0)
+            y = labels[lo:lo + batch_images]
+            with torch.no_grad():
+                out[lo:lo + x.shape[0], 0] = (defense_model(x).argmax(dim=1) == y).float().cpu()
+            for j, attack in enumerate(attacks.values()):
+                if j in per_image:
+                    continue
+                success, bound, _ = attack(x, y, defense_model)
+                success = torch.as_tensor(success).view(-1).cpu()
+                bound = torch.as_tensor(bound, dtype=torch.float32).view(-1).cpu()
+                out[lo:lo + x.shape[0], 1 + j] = torch.where(success, bound, torch.full_like(bound, FAILED))
+        for i in range(images.shape[0]):
+            for j, attack in per_image.items():
+                success, bound, _ = attack(images[i:i + 1].clamp(0.0, 1.0), labels[i:i + 1], defense_model)
+                out[i, 1 + j] = float(bound) if success else FAILED
+        return out
     for i in range(images.shape[0]):
         x = images[i:i + 1].clamp(0.0, 1.0)
         y = labels[i:i + 1]
@@ -102,7 +125,8 @@ def run_worker(rank: int, world: int, args, make_model: Callable, dataset: Tuple
     images, labels = dataset
     mine = shard_indices(images.shape[0], rank, world)
     dev = args.device
-    local = evaluate_shard(defense_model, args.attacks, images[mine].to(dev), labels[mine].to(dev))
+    local = evaluate_shard(defense_model, args.attacks, images[mine].to(dev), labels[mine].to(dev),
+                           batch_images=int(getattr(args, 'batch_images', 1) or 1))
     table = gather_results(local, world, dev)
     res = None
     if rank == 0:
@@ -145,6 +169,8 @@ def parse_args(argv=None):
     p.add_argument('--config', type=str, required=True)
     p.add_argument('--attack', type=str, choices=['deepfool', 'c&w', 'autoattack', 'pgd'], default=None,
                    help='If passed, try a specific attack only. Otherwise, try all (the reference\'s three).')
+    p.add_argument('--batch_images', type=int, default=1,
+                   help='images per defender call for the clean pass and for batched attacks (PGD); 1 = the reference protocol')
     args = p.parse_args(argv)
     args.results_folder = f'./results/{args.config.split("/")[-1][:-5]}/'
     os.makedirs(args.results_folder, exist_ok=True)

@@ -134,6 +134,20 @@ def test_pgd_attack_protocol(setup):
     assert bound <= 8.0 / 255.0 + 1e-6 and 0.0 <= adv.min().item() and adv.max().item() <= 1.0
 
 
+def test_batched_pgd_through_the_driver(setup):
+    """experiments/test_defense.evaluate_shard with batch_images > 1: several images x EoT rows per defender call"""
+    from gen_adversarial_amd.attacks.pgd import PGDLinf
+    from gen_adversarial_amd.experiments.test_defense import FAILED, evaluate_shard
+    args, model, *_ = setup
+    x = torch.rand(5, *RES, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    with torch.no_grad():
+        y = model(x).argmax(dim=1)
+    table = evaluate_shard(model, {'pgd': PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=3)}, x, y, batch_images=4)
+    assert table.shape == (5, 2) and set(table[:, 0].tolist()) <= {0.0, 1.0}
+    d = table[:, 1]
+    assert bool(((d == FAILED) | ((d >= 0) & (d <= 8.0 / 255.0 + 1e-6))).all())
+
+
 def test_reference_attacks_drive_the_hip_defender(setup):
     """DeepFool (per-class backward on one forward), APGD and FGSM against the stochastic HIP defender: protocol and
     invariants (the numbers themselves are pinned on the CPU against the reference, tests/test_attacks_cpu.py)."""

@@ -221,3 +221,24 @@ def test_resnet_plans_build_and_checkpoint_layout(tmp_path):
                         sd[f'{p}.bn2.running_var'], sd[f'{p}.bn2.weight'], sd[f'{p}.bn2.bias'], False, 0.0, 1e-5)
     wf = f['w2'].view(blk.width, 3, 3, blk.width).permute(0, 3, 1, 2)
     torch.testing.assert_close(TF.conv2d(x, wf, f['b2'], stride=2, padding=1), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_batched_evaluation_equals_the_one_image_protocol():
+    """experiments/test_defense.evaluate_shard with batch_images > 1 (batched PGD) returns the per-image table of the
+    reference's one-image-at-a-time loop (deterministic toy classifier)."""
+    import torch
+    from gen_adversarial_amd.attacks.pgd import PGDLinf
+    from gen_adversarial_amd.experiments.test_defense import evaluate_shard
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(1),
+                              torch.nn.Flatten(), torch.nn.Linear(4, 3)).eval()
+    for p in net.parameters():
+        p.requires_grad_(False)
+    x = torch.rand(7, 3, 8, 8)
+    y = net(x).argmax(dim=1)
+    y[2] = (y[2] + 1) % 3                      # one clean-misclassified image
+    attacks = {'pgd': PGDLinf(eps=0.3, step_size=0.05, steps=12)}
+    one = evaluate_shard(net, attacks, x, y, batch_images=1)
+    many = evaluate_shard(net, attacks, x, y, batch_images=3)
+    torch.testing.assert_close(many, one, rtol=0, atol=1e-6)
+    assert one[2, 0] == 0 and one[:, 0].sum() == 6
