@@ -18,8 +18,8 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GA_OPS_LIB') or os.path.join(_HERE, 'libga_ops.so')   # GA_OPS_LIB: debug builds only (make trace)
 
-GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU = 0, 1, 2, 3
-GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT = 1, 2
+GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU, GA_ACT_LRELU = 0, 1, 2, 3, 4
+GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PRELU = 1, 2, 4, 8
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
  GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR, GA_OP_REP_SUM, GA_OP_INTERLEAVE2,
  GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV) = range(1, 18)
@@ -109,7 +109,7 @@ class RepSumDesc(C.Structure):
 
 class Interleave2Desc(C.Structure):
     _fields_ = [('s', fp * 4), ('y', fp), ('dact_x', fp), ('dact_scale', fp), ('dact_shift', fp), ('addend', fp),
-                ('addend2', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dact_act', i32), ('_reserved', i32)]
+                ('addend2', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dact_act', i32), ('dact_prelu', i32)]
 
 
 class Maxpool3s2Desc(C.Structure):

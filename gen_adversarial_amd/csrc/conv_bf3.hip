@@ -187,7 +187,15 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
         for (int i = 0; i < RA; ++i) {
             floatx4 v = ra[set][i];
             if (AFF == 2) v = v * rs[set][i] + rt[set][i];
-            else if (AFF == 1) v = v * rs[set][0] + rt[set][0];
+            else if (AFF == 1) {
+                const floatx4 aff = v * rs[set][0] + rt[set][0];
+                if (d.flags & GA_CONV_PRO_PRELU) {          // uniform: nn.PReLU, the slopes travel in pro_scale
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * rs[set][0][e];
+                } else {
+                    v = aff;
+                }
+            }
             if (ACT == GA_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
@@ -197,6 +205,9 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
             } else if (ACT == GA_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (ACT == GA_ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
             }
             if (AFF != 0) v = (okmask[set] >> i) & 1u ? v : zero;     // act(0) = 0 for all three: only a shift un-zeroes padding
             const bf16x4 hi = __builtin_convertvector(v, bf16x4);
@@ -272,7 +283,7 @@ conv_bf3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C
     // MFMAs of tile t (1 MFMA : 4 VALU : 1 DS, the matrix pipe takes 32 cycles per MFMA, a VALU op 4-8)
     constexpr int NMFMA = TM * TN * 3 * (BK3 / 16);
     // VALU ops of one staged tile: per float4 ~12 for the split, 4 affine, 20 SiLU/ELU, 4 ReLU, 4 padding select
-    constexpr int VOPS = RA * (12 + (AFF ? 8 : 0) + (ACT == GA_ACT_SILU || ACT == GA_ACT_ELU ? 20 : ACT == GA_ACT_RELU ? 4 : 0)) + 8;
+    constexpr int VOPS = RA * (12 + (AFF ? 8 : 0) + (ACT == GA_ACT_SILU || ACT == GA_ACT_ELU ? 20 : ACT == GA_ACT_RELU ? 4 : ACT == GA_ACT_LRELU ? 8 : 0)) + 8;
     constexpr int VPM = (VOPS + NMFMA - 1) / NMFMA;
 #ifndef GA_EXP
 #define GA_EXP 0        // trace builds only: bit 0 drops the split + LDS write, 1 the global loads, 2 the barrier, 3 the MFMAs
@@ -332,7 +343,7 @@ static inline int conv_bf3_mode(const ga_conv_desc& d) {
 // 1 when conv_bf3 has a kernel for this descriptor's prologue (ga_conv2d falls back to the fp32 kernel otherwise)
 int conv_bf3_supports(const ga_conv_desc& d) {
     switch (conv_bf3_mode(d)) {
-        case 0x000: case 0x100: case 0x001: case 0x002: case 0x003: case 0x010: case 0x011: case 0x020: case 0x021: return 1;
+        case 0x000: case 0x100: case 0x001: case 0x002: case 0x003: case 0x004: case 0x010: case 0x011: case 0x020: case 0x021: return 1;
         default: return 0;
     }
 }
@@ -356,6 +367,7 @@ static int launch_bf3(const ga_conv_desc& d, hipStream_t stream, int vec_out, in
         case 0x001: GA_BF3(0, GA_ACT_SILU, false); break;
         case 0x002: GA_BF3(0, GA_ACT_ELU, false); break;
         case 0x003: GA_BF3(0, GA_ACT_RELU, false); break;
+        case 0x004: GA_BF3(0, GA_ACT_LRELU, false); break;
         case 0x010: GA_BF3(1, GA_ACT_NONE, false); break;
         case 0x011: GA_BF3(1, GA_ACT_SILU, false); break;
         case 0x020: GA_BF3(2, GA_ACT_NONE, false); break;

@@ -13,12 +13,18 @@ __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, co
     if (d.dact_x) {
         floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)m * d.lddact + co);
         floatx4 ds = {1.f, 1.f, 1.f, 1.f};
-        if (d.dact_scale) {
+        if (d.flags & GA_CONV_DACT_PRELU) {
             ds = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
-            u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + co);
-        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+            for (int e = 0; e < 4; ++e) v[e] *= u[e] > 0.f ? 1.f : ds[e];
+        } else {
+            if (d.dact_scale) {
+                ds = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
+                u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + co);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+        }
     }
     if (d.addend && !(d.flags & GA_CONV_ADDEND_PRE_DACT)) {
         size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
@@ -37,8 +43,12 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
     if (d.dact_x) {
         float ds = 1.f, db = 0.f;
         if (d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
-        const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
-        v *= act_bwd_fast(u, d.dact_act) * ds;
+        if (d.flags & GA_CONV_DACT_PRELU) {
+            v *= d.dact_x[(size_t)m * d.lddact + co] > 0.f ? 1.f : ds;
+        } else {
+            const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
+            v *= act_bwd_fast(u, d.dact_act) * ds;
+        }
     }
     if (d.addend && !(d.flags & GA_CONV_ADDEND_PRE_DACT)) {
         size_t am = d.addend_bcast_n ? (size_t)(m % HoWo) : (size_t)m;
@@ -129,7 +139,10 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                     floatx4 o = v[k] + bias4;
                     const bool pre = (d.flags & GA_CONV_ADDEND_PRE_DACT) != 0;
                     if (pre && d.addend) o += a1[k];
-                    if (d.dact_x) {
+                    if (d.dact_x && (d.flags & GA_CONV_DACT_PRELU)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] *= u[k][e] > 0.f ? 1.f : ds4[e];
+                    } else if (d.dact_x) {
                         const floatx4 uu = u[k] * ds4 + dt4;
                         if (d.dact_act == GA_ACT_SILU) {
 #pragma unroll

@@ -143,7 +143,14 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
         for (int j = 0; j < RPMAX; ++j) {
             if (j < rp) {
                 floatx4 v = rpat[j];
-                if (AFF == 1) v = v * rs + rt;
+                if (AFF == 1) {
+                    if (d.flags & GA_CONV_PRO_PRELU) {      // uniform: nn.PReLU, the slopes travel in pro_scale
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * rs[e];
+                    } else {
+                        v = v * rs + rt;
+                    }
+                }
                 if (AFF == 2) {     // per-(image, channel) scale / shift: small and L2-resident, fetched as the slot is converted
                     const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow[j] + cur_chunk * HK);
                     const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow[j] + cur_chunk * HK);
@@ -158,6 +165,9 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
                 } else if (ACT == GA_ACT_RELU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (ACT == GA_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
                 if (AFF != 0) v = (okbits >> j) & 1u ? v : zero;        // only a shift un-zeroes the padding
                 const bf16x4 hi = __builtin_convertvector(v, bf16x4);
@@ -314,7 +324,7 @@ int conv_halo3_supports(const ga_conv_desc& d) {
     const int HoWo = d.Ho * d.Wo;
     if (128 % d.Wo != 0 || !(HoWo % 128 == 0 || 128 % HoWo == 0)) return 0;
     switch (halo_mode(d)) {
-        case 0x00: case 0x01: case 0x02: case 0x03: case 0x10: case 0x11: case 0x20: return 1;
+        case 0x00: case 0x01: case 0x02: case 0x03: case 0x04: case 0x10: case 0x11: case 0x20: return 1;
         default: return 0;
     }
 }
@@ -356,6 +366,7 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
         case 0x01: GA_HALO(0, GA_ACT_SILU); break;
         case 0x02: GA_HALO(0, GA_ACT_ELU); break;
         case 0x03: GA_HALO(0, GA_ACT_RELU); break;
+        case 0x04: GA_HALO(0, GA_ACT_LRELU); break;
         case 0x10: GA_HALO(1, GA_ACT_NONE); break;
         case 0x11: GA_HALO(1, GA_ACT_SILU); break;
         case 0x20: GA_HALO(2, GA_ACT_NONE); break;

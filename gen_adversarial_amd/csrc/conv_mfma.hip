@@ -220,7 +220,9 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                             const int ce = c + e;
                             if (ce < d.C1) {
                                 float u = d.x[pix * d.ldx + ce];
-                                if (d.pro_scale) {
+                                if (d.pro_scale && (d.flags & GA_CONV_PRO_PRELU)) {
+                                    u = u > 0.f ? u : u * d.pro_scale[ce];
+                                } else if (d.pro_scale) {
                                     const size_t po = (d.pro_per_row ? (size_t)a_n[i] * d.C1 : 0) + ce;
                                     u = u * d.pro_scale[po] + d.pro_shift[po];
                                 }
@@ -259,7 +261,10 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                 if (PRO != 0) {
                     floatx4 pv = v;
                     if (PRO == 2) pv = pv * rs[i] + rt[i];
-                    else if (d.pro_scale) pv = pv * rs[0] + rt[0];
+                    else if (d.pro_scale && (d.flags & GA_CONV_PRO_PRELU)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] = pv[e] > 0.f ? pv[e] : pv[e] * rs[0][e];
+                    } else if (d.pro_scale) pv = pv * rs[0] + rt[0];
                     if (d.pro_act == GA_ACT_SILU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);
@@ -282,7 +287,10 @@ conv_mfma_kernel(const ga_conv_desc d, const int tilesN, const int M, const int 
                 if (PRO != 0) {
                     floatx4 pv = v;
                     if (PRO == 2) pv = pv * rs[i] + rt[i];
-                    else if (d.pro_scale) pv = pv * rs[0] + rt[0];
+                    else if (d.pro_scale && (d.flags & GA_CONV_PRO_PRELU)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pv[e] = pv[e] > 0.f ? pv[e] : pv[e] * rs[0][e];
+                    } else if (d.pro_scale) pv = pv * rs[0] + rt[0];
                     if (d.pro_act == GA_ACT_SILU) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) pv[e] = pv[e] * fast_sigmoid(pv[e]);

@@ -604,12 +604,18 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const ga_interleave2_d
         if (d.dact_x) {
             floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
             floatx4 ds = {1.f, 1.f, 1.f, 1.f};
-            if (d.dact_scale) {
+            if (d.dact_prelu) {
                 ds = *reinterpret_cast<const floatx4*>(d.dact_scale + 4 * q);
-                u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + 4 * q);
-            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+                for (int e = 0; e < 4; ++e) v[e] *= u[e] > 0.f ? 1.f : ds[e];
+            } else {
+                if (d.dact_scale) {
+                    ds = *reinterpret_cast<const floatx4*>(d.dact_scale + 4 * q);
+                    u = u * ds + *reinterpret_cast<const floatx4*>(d.dact_shift + 4 * q);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act) * ds[e];
+            }
         }
         if (d.addend) v += *reinterpret_cast<const floatx4*>(d.addend + o);
         if (d.addend2) v += *reinterpret_cast<const floatx4*>(d.addend2 + o);
@@ -847,7 +853,8 @@ extern "C" int ga_interleave2(const ga_interleave2_desc* d, void* s) {
     ga::clear_stale_error();
     if (!d || !d->y || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
     if (((d->H | d->W) & 1) || (d->C % 4)) return GA_E_UNSUPPORTED;
-    if ((d->dact_scale == nullptr) != (d->dact_shift == nullptr)) return GA_E_BADARG;
+    if ((d->dact_scale == nullptr) != (d->dact_shift == nullptr) && !d->dact_prelu) return GA_E_BADARG;
+    if (d->dact_prelu && (!d->dact_x || !d->dact_scale)) return GA_E_BADARG;
     const long total4 = (long)d->N * d->H * d->W * (d->C / 4);
     hipLaunchKernelGGL(interleave2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();

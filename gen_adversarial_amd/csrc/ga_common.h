@@ -18,6 +18,7 @@ __device__ __forceinline__ float act_fwd(float u, int act) {
         case GA_ACT_SILU: return u * sigmoidf_(u);
         case GA_ACT_ELU:  return u > 0.0f ? u : expm1f(u);
         case GA_ACT_RELU: return fmaxf(u, 0.0f);
+        case GA_ACT_LRELU: return u > 0.0f ? u : 0.01f * u;
         default:          return u;
     }
 }
@@ -28,6 +29,7 @@ __device__ __forceinline__ float act_bwd(float u, int act) {
         case GA_ACT_SILU: { float s = sigmoidf_(u); return s * (1.0f + u * (1.0f - s)); }
         case GA_ACT_ELU:  return u > 0.0f ? 1.0f : expf(u);
         case GA_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+        case GA_ACT_LRELU: return u > 0.0f ? 1.0f : 0.01f;
         default:          return 1.0f;
     }
 }
@@ -41,6 +43,7 @@ __device__ __forceinline__ float act_fwd_fast(float u, int act) {
         case GA_ACT_SILU: return u * fast_sigmoid(u);
         case GA_ACT_ELU:  return u > 0.0f ? u : expm1f(u);          // rare on the path: keep libm accuracy near 0
         case GA_ACT_RELU: return fmaxf(u, 0.0f);
+        case GA_ACT_LRELU: return u > 0.0f ? u : 0.01f * u;
         default:          return u;
     }
 }
@@ -50,6 +53,7 @@ __device__ __forceinline__ float act_bwd_fast(float u, int act) {
         case GA_ACT_SILU: { float s = fast_sigmoid(u); return s * (1.0f + u * (1.0f - s)); }
         case GA_ACT_ELU:  return u > 0.0f ? 1.0f : expf(u);
         case GA_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
+        case GA_ACT_LRELU: return u > 0.0f ? 1.0f : 0.01f;
         default:          return 1.0f;
     }
 }

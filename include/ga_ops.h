@@ -29,12 +29,16 @@ extern "C" {
 #define GA_E_UNSUPPORTED -3  /* shape outside what the kernel implements */
 #define GA_E_LAUNCH     -4   /* hipLaunch failed (see ga_last_hip_error) */
 
-enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3 };
+enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3,
+              GA_ACT_LRELU = 4 /* nn.LeakyReLU(): slope 0.01 (GradualStyleBlock, encoding/encoder.py:41-46) */ };
 /* ga_conv_desc.flags — residual networks that keep PRE-activation sums (torchvision Bottleneck: out = relu(f(x) + identity)):
  *   GA_CONV_ADDEND_RELU     forward : y = ... + relu(addend)            (the identity branch is relu of the stored pre-activation)
  *   GA_CONV_ADDEND_PRE_DACT backward: y = (acc + addend) * act'(dact_x) (+ addend2): the identity branch's cotangent passes
  *                                      through the same act' as the convolution branch's */
-enum ga_conv_flags { GA_CONV_ADDEND_RELU = 1, GA_CONV_ADDEND_PRE_DACT = 2 };
+/*   GA_CONV_PRO_PRELU       prologue = nn.PReLU(C): x -> x > 0 ? x : pro_scale[c] * x  (pro_scale = the slopes, pro_shift any
+ *                           non-NULL pointer, pro_act GA_ACT_NONE, per-channel form) — bottleneck_IR_SE, encoding/helpers.py:112
+ *   GA_CONV_DACT_PRELU      epilogue act' of the same: y *= dact_x > 0 ? 1 : dact_scale[c]  (dact_shift any non-NULL pointer) */
+enum ga_conv_flags { GA_CONV_ADDEND_RELU = 1, GA_CONV_ADDEND_PRE_DACT = 2, GA_CONV_PRO_PRELU = 4, GA_CONV_DACT_PRELU = 8 };
 
 /* ------------------------------------------------------------------------------------------------------------------
  * ga_conv2d — dense convolution as an fp32-MFMA implicit GEMM (v_mfma_f32_32x32x2_f32, exact fp32 fma chains).
@@ -284,7 +288,7 @@ typedef struct ga_interleave2_desc {
     const float* addend; const float* addend2;                              /* [N,H,W,C] or NULL */
     int N, H, W, C;           /* output size; H, W even, C % 4 == 0 */
     int dact_act;             /* ga_act */
-    int _reserved;
+    int dact_prelu;           /* 1: act' = dact_x > 0 ? 1 : dact_scale[c] (nn.PReLU slopes in dact_scale, dact_shift ignored) */
 } ga_interleave2_desc;
 int ga_interleave2(const ga_interleave2_desc* d, void* stream);
 

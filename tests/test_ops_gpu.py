@@ -556,6 +556,47 @@ def test_avgpool_act():
     close(dx.cpu(), gx, 1e-6, 'avgpool bwd')
 
 
+@pytest.mark.parametrize('bf3,tile,K', [(False, 0, 3), (True, 1, 3), (True, 5, 3), (True, 2, 1)])
+def test_conv_prelu_and_leaky_relu(bf3, tile, K):
+    """nn.PReLU(C) as prologue (GA_CONV_PRO_PRELU) and its derivative as epilogue (GA_CONV_DACT_PRELU); nn.LeakyReLU()
+    as GA_ACT_LRELU — e4e's bottleneck_IR_SE and GradualStyleBlock (encoding/helpers.py:112, encoder.py:41-46)"""
+    N, H, Cin, Cout = 2, 16, 64, 96
+    x = g(N, Cin, H, H, seed=1)
+    w = g(Cout, Cin, K, K, seed=2, scale=1.0 / np.sqrt(Cin * K * K))
+    slope = (torch.rand(Cin, generator=torch.Generator().manual_seed(3)) - 0.3)          # both signs
+    wf = fwd_w(w)
+    kw = {}
+    if bf3:
+        hi = wf.to(torch.bfloat16)
+        kw = dict(w_hi=hi, w_lo=(wf - hi.float()).to(torch.bfloat16))
+    tol = 2e-4 if bf3 else 2e-5
+    for mode in ('prelu', 'lrelu'):
+        xr = x.clone().requires_grad_(True)
+        a = F.prelu(xr, slope) if mode == 'prelu' else F.leaky_relu(xr, 0.01)
+        ref = F.conv2d(a, w, padding=K // 2)
+        y = torch.full((N, H, H, Cout), float('nan'), device=DEV)
+        sl = slope.to(DEV)
+        if mode == 'prelu':
+            run_conv(nhwc(x), wf, y, K, pad=K // 2, tile=tile, pro_scale=sl, pro_shift=sl, flags=L.GA_CONV_PRO_PRELU, **kw)
+        else:
+            run_conv(nhwc(x), wf, y, K, pad=K // 2, tile=tile, pro_act=L.GA_ACT_LRELU, **kw)
+        close(nchw(y), ref, tol, f'{mode} prologue')
+        cot = g(*ref.shape, seed=6)
+        (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+        wb = bwd_w(w)
+        kb = {}
+        if bf3:
+            bh = wb.to(torch.bfloat16)
+            kb = dict(w_hi=bh, w_lo=(wb - bh.float()).to(torch.bfloat16))
+        dx = torch.full((N, H, H, Cin), float('nan'), device=DEV)
+        if mode == 'prelu':
+            run_conv(nhwc(cot), wb, dx, K, pad=K // 2, tile=tile, dact_x=nhwc(x), lddact=Cin, dact_scale=sl, dact_shift=sl,
+                     flags=L.GA_CONV_DACT_PRELU, **kb)
+        else:
+            run_conv(nhwc(cot), wb, dx, K, pad=K // 2, tile=tile, dact_x=nhwc(x), lddact=Cin, dact_act=L.GA_ACT_LRELU, **kb)
+        close(nchw(dx), gx, tol, f'{mode} epilogue')
+
+
 @pytest.mark.parametrize('Cout,splits', [(64, 1), (20, 1), (64, 2)])
 def test_conv_residual_flags(Cout, splits):
     """GA_CONV_ADDEND_RELU (y = conv + relu(addend)) and GA_CONV_ADDEND_PRE_DACT (y = (conv + addend) * act'(u)) in the
