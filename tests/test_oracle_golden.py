@@ -118,3 +118,22 @@ def test_dml_mean_and_normal():
     np.testing.assert_allclose(sigma.numpy(), g['normal_sigma'], atol=1e-5, rtol=1e-6)
     z = mu + _t(g['normal_eps']) * sigma
     np.testing.assert_allclose(z.numpy(), g['normal_z'], atol=1e-5, rtol=1e-6)
+
+
+def test_e4e_oracle_matches_the_reference_encoder():
+    """oracle/e4e_oracle.py against the reference's Encoder4Editing (tests/golden/make_e4e_golden.py): latents and input
+    gradient of the full-width IR-SE50 + FPN + 10 style heads on 64x64 inputs"""
+    import os
+    import numpy as np
+    import torch
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from oracle.e4e_oracle import e4e_encode
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'e4e_ir50_s64.npz'))
+    size, seed = int(g['stylegan_size']), int(g['seed'])
+    spec = build_e4e_spec(size)
+    sd = init_e4e_state_dict(size, 1, seed)
+    x = torch.from_numpy(g['x']).requires_grad_(True)
+    w = e4e_encode(sd, spec, x)
+    (gx,) = torch.autograd.grad((w * torch.from_numpy(g['cot'])).sum(), [x])
+    assert (w.detach() - torch.from_numpy(g['w'])).abs().max().item() < 1e-5
+    assert (gx - torch.from_numpy(g['gx'])).abs().max().item() < 1e-5 * max(1.0, float(np.abs(g['gx']).max()))
