@@ -184,6 +184,8 @@ __global__ void __launch_bounds__(256) se_apply_kernel(const ga_se_apply_desc d,
         floatx4 s;
         if (d.skip_mode == 0) {
             s = *reinterpret_cast<const floatx4*>(d.skip + i * 4);
+        } else if (d.skip_mode == 2) {
+            s = *reinterpret_cast<const floatx4*>(d.skip + (((size_t)n * 2 * d.H + 2 * h) * 2 * d.W + 2 * w) * d.C + c);
         } else {
             const int hl = d.H / 2, wl = d.W / 2;
             int h0, h1, w0, w1; float lh, lw;
@@ -463,6 +465,28 @@ __global__ void __launch_bounds__(256) maxpool3s2_kernel(const ga_maxpool3s2_des
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// nn.PReLU as its own pass (forward / backward)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) prelu_kernel(const ga_prelu_desc d, const long total4) {
+    const int C4 = d.C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const floatx4 a = ld4(d.slope + 4 * (int)(i % C4));
+        const floatx4 x = ld4(d.x + i * 4);
+        floatx4 r;
+        if (!d.backward) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = x[e] > 0.f ? x[e] : a[e] * x[e];
+            *reinterpret_cast<floatx4*>(d.y + i * 4) = r;
+        } else {
+            const floatx4 g = ld4(d.dy + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = g[e] * (x[e] > 0.f ? 1.f : a[e]);
+            *reinterpret_cast<floatx4*>(d.dx + i * 4) = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // grouped convolution, few channels per group (ResNeXt conv2 and the sub-kernels of its transposes): one thread per
 // output pixel x output-channel quad; the quads of a group read the same input channels (L1 broadcast), weights from L1/L2
 // ---------------------------------------------------------------------------------------------------------------
@@ -735,7 +759,7 @@ extern "C" int ga_se_apply(const ga_se_apply_desc* d, void* s) {
     if (!d || !d->skip || !d->t || !d->gate || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (d->skip_mode == 1 && ((d->H | d->W) & 1)) return GA_E_BADARG;
-    if (d->skip_mode != 0 && d->skip_mode != 1) return GA_E_UNSUPPORTED;
+    if (d->skip_mode < 0 || d->skip_mode > 2) return GA_E_UNSUPPORTED;
     if (!aligned16(d->skip) || !aligned16(d->t) || !aligned16(d->gate) || !aligned16(d->out)) return GA_E_ALIGN;
     const long total4 = (long)d->N * d->H * d->W * (d->C / 4);
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
@@ -800,6 +824,17 @@ extern "C" int ga_maxpool3s2(const ga_maxpool3s2_desc* d, void* s) {
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
     const long total4 = d->backward ? (long)d->N * d->H * d->W * (d->C / 4) : (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
     hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_prelu(const ga_prelu_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || !d->slope || d->rows <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && !d->y) return GA_E_BADARG;
+    if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    const long total4 = d->rows * (d->C / 4);
+    hipLaunchKernelGGL(prelu_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }
 

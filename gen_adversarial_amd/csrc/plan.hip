@@ -22,6 +22,7 @@ static int run_one(const ga_op& op, void* stream) {
         case GA_OP_MAXPOOL3S2:   return ga_maxpool3s2(&op.u.mp3, stream);
         case GA_OP_AVGPOOL_ACT:  return ga_avgpool_act(&op.u.ap, stream);
         case GA_OP_GCONV:        return ga_gconv(&op.u.gc, stream);
+        case GA_OP_PRELU:        return ga_prelu(&op.u.pr, stream);
         case GA_OP_AXPBY:        return ga_axpby(op.u.ax.x, op.u.ax.y, op.u.ax.n, op.u.ax.alpha, op.u.ax.beta, stream);
         default:                 return GA_E_UNSUPPORTED;
     }

@@ -295,3 +295,68 @@ def fold_resnet_head(sd: SD) -> dict:
     w3 = sd['model.fc.3.weight']
     return {'w_h': f32(w0), 'w_h_bwd': f32(w0.t()), 'b_h': f32(t),
             'w_o': f32(w3), 'w_o_bwd': f32(w3.t()), 'b_o': f32(sd['model.fc.3.bias'])}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# e4e encoder (encoding/encoder.py, encoding/helpers.py; spec in e4e_spec.py)
+# ---------------------------------------------------------------------------------------------------------------
+
+def fold_e4e_input(sd: SD, ld: int) -> dict:
+    """input_layer: Conv2d(3, 64, 3, 1, 1, bias=False) + BatchNorm2d folded; PReLU slopes kept apart (encoder.py:72-74)"""
+    w, b = _conv_bn64(sd, 'input_layer.0', 'input_layer.1')
+    out = pad_image_conv({'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(b)}, 3, ld)
+    out['slope'] = f32(sd['input_layer.2.weight'])
+    return out
+
+
+def fold_ir_se_unit(sd: SD, u) -> dict:
+    """bottleneck_IR_SE (helpers.py:97-119): BN0 stays a prologue affine of conv1 (zero padding applies AFTER the BN, so its
+    shift cannot move into a bias), BN4 folds into conv2, the SE FCs are bias-free 1x1 convs, the conv shortcut folds its BN."""
+    p = u.prefix
+    s0, t0 = bn_affine64(sd, f'{p}.res_layer.0')
+    w1 = sd[f'{p}.res_layer.1.weight'].double()
+    w2, b2 = _conv_bn64(sd, f'{p}.res_layer.3', f'{p}.res_layer.4')
+    hid = sd[f'{p}.res_layer.5.fc1.weight'].shape[0]
+    out = {'pro_scale': f32(s0), 'pro_shift': f32(t0),
+           'w1': f32(conv_fwd_layout(w1)), 'w1_bwd': f32(conv_bwd_layout(w1)),
+           'slope': f32(sd[f'{p}.res_layer.2.weight']),
+           'w2': f32(conv_fwd_layout(w2)), 'b2': f32(b2),
+           'se_w1': f32(sd[f'{p}.res_layer.5.fc1.weight'][:, :, 0, 0]), 'se_b1': torch.zeros(hid),
+           'se_w2': f32(sd[f'{p}.res_layer.5.fc2.weight'][:, :, 0, 0]), 'se_b2': torch.zeros(u.depth)}
+    if u.stride == 1:
+        out['w2_bwd'] = f32(conv_bwd_layout(w2))
+    else:
+        for (a, b), (wm, kh, kw) in subpixel_weights(w2).items():
+            out[f'w2_sub{a}{b}'] = wm
+    if u.cin != u.depth:
+        ws, bs = _conv_bn64(sd, f'{p}.shortcut_layer.0', f'{p}.shortcut_layer.1')
+        out['ws'], out['bs'] = f32(conv_fwd_layout(ws)), f32(bs)
+        if u.stride == 1:
+            out['ws_bwd'] = f32(conv_bwd_layout(ws))
+        else:
+            for (a, b), (wm, kh, kw) in subpixel_weights(ws).items():
+                out[f'ws_sub{a}{b}'] = wm
+    return out
+
+
+def fold_e4e_lateral(sd: SD, name: str) -> dict:
+    w = sd[f'{name}.weight'].double()
+    return {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'b': f32(sd[f'{name}.bias'])}
+
+
+def fold_e4e_style(sd: SD, j: int, pools: int) -> dict:
+    """GradualStyleBlock (encoder.py:33-54): `pools` stride-2 3x3 convs with bias (LeakyReLU between: a consumer prologue)
+    and the EqualLinear (lr_mul = 1: weight * 1/sqrt(in), bias as is; generator.py:85-98).  Per conv: forward weights,
+    sub-pixel backward kernels, and the centre tap as a 1x1 conv for maps that are already 1x1 (small test inputs)."""
+    out = {}
+    for k in range(pools):
+        w = sd[f'styles.{j}.convs.{2 * k}.weight'].double()
+        out[f'w{k}'], out[f'b{k}'] = f32(conv_fwd_layout(w)), f32(sd[f'styles.{j}.convs.{2 * k}.bias'])
+        for (a, b), (wm, kh, kw) in subpixel_weights(w).items():
+            out[f'w{k}_sub{a}{b}'] = wm
+        wc = w[:, :, 1:2, 1:2]
+        out[f'w{k}_c'], out[f'w{k}_c_bwd'] = f32(conv_fwd_layout(wc)), f32(conv_bwd_layout(wc))
+    wl = sd[f'styles.{j}.linear.weight'].double()
+    wl = wl * (1.0 / (wl.shape[1] ** 0.5))
+    out['wl'], out['wl_bwd'], out['bl'] = f32(wl), f32(wl.t()), f32(sd[f'styles.{j}.linear.bias'])
+    return out

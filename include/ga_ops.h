@@ -144,7 +144,8 @@ typedef struct ga_se_excite_desc {
 int ga_se_excite(const ga_se_excite_desc* d, void* stream);
 
 /* out[n,h,w,c] = skip(n,h,w,c) + res_scale * gate[n,c] * t[n,h,w,c]
- * skip_mode 0: skip is [N,H,W,C]; 1: skip is [N,H/2,W/2,C] read through bilinear x2, align_corners=True
+ * skip_mode 0: skip is [N,H,W,C]; 1: skip is [N,H/2,W/2,C] read through bilinear x2, align_corners=True;
+ * 2: skip is [N,2H,2W,C] sub-sampled at the even pixels (MaxPool2d(1, 2) shortcut of bottleneck_IR_SE, helpers.py:100-101)
  * (SkipUp, architecture.py:91-93; the 1x1 conv commutes with the interpolation and is applied at low resolution). */
 typedef struct ga_se_apply_desc {
     const float* skip; const float* t; const float* gate; float* out;
@@ -221,6 +222,14 @@ typedef struct ga_gconv_desc {
     int _reserved;
 } ga_gconv_desc;
 int ga_gconv(const ga_gconv_desc* d, void* stream);
+
+/* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
+ * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
+ * x: [rows][C], C % 4 == 0. */
+typedef struct ga_prelu_desc {
+    const float* x; const float* slope; float* y; const float* dy; float* dx; long rows; int C; int backward;
+} ga_prelu_desc;
+int ga_prelu(const ga_prelu_desc* d, void* stream);
 
 /* 3x3 / stride 2 / pad 1 max pool (torchvision ResNet stem, resnet.py `self.maxpool`), on pre-activation maps (ReLU
  * commutes with max).  x: [N,H,W,C], y: [N,H/2,W/2,C] (H, W even).  backward: dx[p] = sum of dy over the windows whose
@@ -301,7 +310,7 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
-                  GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17 };
+                  GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -311,7 +320,7 @@ typedef struct ga_op {
         ga_conv_desc conv; ga_dwconv5_desc dw; ga_rowchan_reduce_desc red; ga_se_excite_desc se; ga_se_apply_desc app;
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
-        ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc;
+        ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */
