@@ -5,8 +5,11 @@ import torch
 from gen_adversarial_amd.engine import Engine
 from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-spec = build_resnet_spec(2); sd = init_resnet_state_dict(2, 1, 0)
-eng = Engine(None, None, (3, 256, 256), sd, spec, rows=rows, rep=1, alphas=[], device='cuda:0')
+next50 = len(sys.argv) > 2 and sys.argv[2] == 'resnext'
+spec = build_resnet_spec(4, 1, (3, 4, 6, 3), 32, 4) if next50 else build_resnet_spec(2)
+sd = init_resnet_state_dict(4, 1, 0, (3, 4, 6, 3), 32, 4) if next50 else init_resnet_state_dict(2, 1, 0)
+res = 128 if next50 else 256
+eng = Engine(None, None, (3, res, res), sd, spec, rows=rows, rep=1, alphas=[], device='cuda:0')
 eng.x_in.uniform_(); eng.forward(); eng.dlogits.normal_(); eng.backward(); torch.cuda.synchronize()
 s = eng.stream()
 for plan, tag in ((eng.fwd, 'fwd'), (eng.bwd, 'bwd')):
