@@ -532,6 +532,58 @@ __global__ void __launch_bounds__(256) gconv_kernel(const ga_gconv_desc d, const
     }
 }
 
+// one thread = one output pixel x ALL cg output channels of one group (grid.y); the group's weights sit in LDS and are read
+// as wave-wide broadcasts, the pixel's input channels come from global memory once per tap: 4*cg FMAs per LDS read
+template <int CG>
+__global__ void __launch_bounds__(256) gconv_group_kernel(const ga_gconv_desc d, const long npix) {
+    extern __shared__ __attribute__((aligned(16))) float gw[];          // [CG out][KH*KW][CG in]
+    const int g = blockIdx.y, taps = d.KH * d.KW, K = taps * CG;
+    for (int i = threadIdx.x * 4; i < CG * K; i += 256 * 4)
+        *reinterpret_cast<floatx4*>(gw + i) = ld4(d.w + (size_t)g * CG * K + i);
+    __syncthreads();
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const int wo = (int)(p % d.Wo); long q = p / d.Wo;
+    const int ho = (int)(q % d.Ho); const int n = (int)(q / d.Ho);
+    float acc[CG];
+#pragma unroll
+    for (int o = 0; o < CG; ++o) acc[o] = d.bias ? d.bias[g * CG + o] : 0.f;
+    for (int kh = 0; kh < d.KH; ++kh) {
+        const int h = ho * d.stride - d.pad + kh;
+        if (h < 0 || h >= d.Hi) continue;
+        for (int kw = 0; kw < d.KW; ++kw) {
+            const int w = wo * d.stride - d.pad + kw;
+            if (w < 0 || w >= d.Wi) continue;
+            const float* xp = d.x + (((size_t)n * d.Hi + h) * d.Wi + w) * d.C + g * CG;
+            const float* wp = gw + (kh * d.KW + kw) * CG;
+#pragma unroll
+            for (int c = 0; c < CG; c += 4) {
+                floatx4 v = ld4(xp + c);
+                if (d.pro_act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
+                }
+#pragma unroll
+                for (int o = 0; o < CG; ++o) {
+                    const floatx4 w4 = *reinterpret_cast<const floatx4*>(wp + o * K + c);
+                    acc[o] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+                }
+            }
+        }
+    }
+    const size_t ob = (size_t)p * d.C + g * CG;
+#pragma unroll
+    for (int o = 0; o < CG; o += 4) {
+        floatx4 r = {acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+        if (d.dact_x) {
+            const floatx4 u = ld4(d.dact_x + ob + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] *= act_bwd_fast(u[e], d.dact_act);
+        }
+        *reinterpret_cast<floatx4*>(d.y + ob + o) = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // global average pool with an activation prologue (torchvision ResNet avgpool after the last ReLU)
 // ---------------------------------------------------------------------------------------------------------------
@@ -845,7 +897,19 @@ extern "C" int ga_gconv(const ga_gconv_desc* d, void* s) {
     if (d->cg % 4) return GA_E_UNSUPPORTED;
     if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->y) || (d->bias && !aligned16(d->bias)) ||
         (d->dact_x && !aligned16(d->dact_x))) return GA_E_ALIGN;
-    const long total4 = (long)d->N * d->Ho * d->Wo * (d->C / 4);
+    const long npix = (long)d->N * d->Ho * d->Wo;
+    const size_t lds = (size_t)d->cg * d->KH * d->KW * d->cg * sizeof(float);
+    const dim3 grid((unsigned)((npix + 255) / 256), (unsigned)(d->C / d->cg));
+    if (npix < 0x7fffffffL * 256 && lds <= 64 * 1024) {         // one pixel x one whole group per thread, weights in LDS
+        switch (d->cg) {
+            case 4:  hipLaunchKernelGGL(gconv_group_kernel<4>, grid, dim3(256), lds, (hipStream_t)s, *d, npix); return check_launch();
+            case 8:  hipLaunchKernelGGL(gconv_group_kernel<8>, grid, dim3(256), lds, (hipStream_t)s, *d, npix); return check_launch();
+            case 16: hipLaunchKernelGGL(gconv_group_kernel<16>, grid, dim3(256), lds, (hipStream_t)s, *d, npix); return check_launch();
+            case 32: hipLaunchKernelGGL(gconv_group_kernel<32>, grid, dim3(256), lds, (hipStream_t)s, *d, npix); return check_launch();
+            default: break;
+        }
+    }
+    const long total4 = npix * (d->C / 4);
     hipLaunchKernelGGL(gconv_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }

@@ -644,7 +644,7 @@ def test_image_io():
     close(dx, gx, 1e-6, 'image bwd')
 
 
-@pytest.mark.parametrize('stride,cg,act', [(1, 4, 3), (2, 8, 3), (1, 16, 0)])
+@pytest.mark.parametrize('stride,cg,act', [(1, 4, 3), (2, 8, 3), (1, 16, 0), (2, 32, 3), (1, 12, 3)])
 def test_gconv(stride, cg, act):
     """grouped conv (ResNeXt conv2) forward with ReLU prologue, and as its own backward-to-input (stride 1) with act'"""
     from gen_adversarial_amd.folding import conv_fwd_layout, grouped_bwd_weights
