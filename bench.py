@@ -147,8 +147,10 @@ def clone_engine(eng, model, device, args):
                   share_encoder=args.share_encoder, store=eng.store)
 
 
-def cpu_baseline(model, rows, rep):
-    """the oracle (CPU restatement) on the host cores: one attack step (forward + input-gradient) on `rows` rows."""
+def cpu_baseline(model, rows, rep, check=None):
+    """the oracle (CPU restatement) on the host cores: one attack step (forward + input-gradient) on `rows` rows.
+    `check(x, eps, logits, grad)`, when given, receives the oracle's inputs and results after the timed part (the
+    caller replays them on the HIP path: a full-size parity figure next to the timing)."""
     from oracle import defender_oracle as D
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, build_spec
     sd, vsd, vspec, alphas = model
@@ -168,8 +170,10 @@ def cpu_baseline(model, rows, rep):
     logits, _ = D.nvae_defender(sd, spec, vsd, vspec, x.repeat_interleave(rep, dim=0), alphas, eps, noise, 0.0)
     mean = logits.view(-1, rep, logits.shape[-1]).mean(dim=1)
     loss = torch.nn.functional.cross_entropy(mean, mean.argmax(dim=1).detach(), reduction='sum')
-    torch.autograd.grad(loss, [x])
+    (gx,) = torch.autograd.grad(loss, [x])
     dt = time.time() - t0
+    if check is not None:
+        check(x.detach(), eps, logits.detach(), gx)
     return {'value': rows / dt, 'unit': 'rows/s', 'cores': threads, 'kind': 'port',
             'sample': f'{rows // rep} image(s) x EoT {rep} = {rows} rows, one attack step (forward + input-gradient), '
                       f'{dt:.1f} s of oracle (PyTorch CPU fp32) time, dX only'}
@@ -339,7 +343,26 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 log('cpu baseline (oracle on host cores) ...')
-                out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot)
+                def parity(xc, epsc, lc, gc):
+                    # the same 128 rows on the HIP path (oracle as the checker): logits and input gradient of the CE loss
+                    e = build_model(device, xc.shape[0] * args.eot, args.eot, seed=0, precision=args.precision, store=eng.store)[0]
+                    e.x_in.copy_(xc.to(device))
+                    for b_, e_ in zip(e.eps, epsc):
+                        b_.copy_(e_.to(device))
+                    e.forward()
+                    lg = e.logits.view(-1, args.eot, e.logits.shape[-1]).mean(dim=1)
+                    p = torch.softmax(lg, dim=1)
+                    p[torch.arange(p.shape[0], device=p.device), lg.argmax(dim=1)] -= 1.0
+                    e.dlogits.view(-1, args.eot, p.shape[-1]).copy_((p / args.eot).unsqueeze(1).expand(-1, args.eot, -1))
+                    e.backward()
+                    ref_mean = lc.view(-1, args.eot, lc.shape[-1]).mean(dim=1)
+                    gd = (e.dx.cpu() - gc).double()
+                    out['parity_vs_oracle'] = {
+                        'rows': int(lc.shape[0]), 'max_abs_logit_err': float((e.logits.cpu() - lc).abs().max()),
+                        'argmax_agree': int((lg.argmax(dim=1).cpu() == ref_mean.argmax(dim=1)).sum()), 'images': int(ref_mean.shape[0]),
+                        'input_grad_rel_l2': float(gd.norm() / gc.double().norm()),
+                        'note': 'same inputs and latent noise as the cpu_baseline sample; tolerance of the path: 1e-3 on logits'}
+                out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)
                 log('cpu baseline done')
             except Exception as ex:   # the baseline is a reported number, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'rows/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {ex}'}
