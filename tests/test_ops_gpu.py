@@ -303,6 +303,74 @@ def test_stride2_transpose_by_subpixel_convs(k, bf3):
     close(nchw(out), gx + prev, 2e-4 if bf3 else 2e-5, f'sub-pixel transpose k{k}')
 
 
+def _fuzz_cases(n, seed):
+    rs = np.random.RandomState(seed)
+    cases = []
+    while len(cases) < n:
+        K = int(rs.choice([1, 1, 3, 3, 3, 5]))
+        stride = int(rs.choice([1, 1, 1, 2]))
+        c = dict(N=int(rs.randint(1, 5)), H=int(rs.choice([4, 6, 8, 12, 16])), W=int(rs.choice([4, 8, 10, 16])),
+                 Cin=int(rs.choice([4, 8, 20, 32, 48, 64, 96])), Cout=int(rs.choice([4, 12, 32, 40, 64, 100, 160])),
+                 K=K, stride=stride, act=int(rs.randint(0, 5)), aff=int(rs.choice([0, 0, 1, 2])), bf3=bool(rs.randint(0, 2)),
+                 tile=int(rs.choice([0, 0, 1, 2, 3, 4, 5, 6])), addend=bool(rs.randint(0, 2)), dact=int(rs.choice([0, 0, 1, 3, 4])),
+                 splits=int(rs.choice([1, 1, 1, 2, 3])), seed=int(rs.randint(1 << 30)))
+        if c['H'] % stride or c['W'] % stride:
+            continue
+        cases.append(c)
+    return cases
+
+
+@pytest.mark.parametrize('c', _fuzz_cases(48, 2024), ids=lambda c: 'N{N}_{H}x{W}_{Cin}to{Cout}_k{K}s{stride}_a{act}f{aff}_b{bf3}_t{tile}_s{splits}'.format(**c))
+def test_conv_randomised_descriptors(c):
+    """seeded random convolution descriptors (non-square images, odd channel counts, every prologue / epilogue feature,
+    tile request, split-K, both arithmetic paths) against the same op composed in torch; a request the library refuses
+    (GA_E_UNSUPPORTED for a tile that cannot take the shape) must be refused without writing the output"""
+    N, H, W, Cin, Cout, K, st = c['N'], c['H'], c['W'], c['Cin'], c['Cout'], c['K'], c['stride']
+    gen = torch.Generator().manual_seed(c['seed'])
+    x = torch.randn(N, Cin, H, W, generator=gen)
+    w = torch.randn(Cout, Cin, K, K, generator=gen) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=gen)
+    Ho, Wo = H // st, W // st
+    u = x
+    kw = {}
+    if c['aff'] == 1:
+        sc, sh = torch.rand(Cin, generator=gen) + 0.5, torch.randn(Cin, generator=gen) * 0.3
+        u = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV))
+    elif c['aff'] == 2:
+        sc, sh = torch.rand(N, Cin, generator=gen) + 0.5, torch.randn(N, Cin, generator=gen) * 0.3
+        u = x * sc.view(N, Cin, 1, 1) + sh.view(N, Cin, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV), pro_per_row=1)
+    acts = {0: lambda t: t, 1: F.silu, 2: F.elu, 3: F.relu, 4: lambda t: F.leaky_relu(t, 0.01)}
+    ref = F.conv2d(acts[c['act']](u), w, b, stride=st, padding=K // 2)
+    assert ref.shape[2:] == (Ho, Wo) or K // 2 * 2 + 1 != K
+    if c['dact']:
+        v = torch.randn(N, Cout, Ho, Wo, generator=gen)
+        vr = v.clone().requires_grad_(True)
+        (dv,) = torch.autograd.grad(acts[c['dact']](vr).sum(), [vr])
+        ref = ref * dv
+        kw.update(dact_x=nhwc(v), lddact=Cout, dact_act=c['dact'])
+    if c['addend']:
+        a = torch.randn(N, Cout, Ho, Wo, generator=gen)
+        ref = ref + a
+        kw.update(addend=nhwc(a), ldadd=Cout)
+    wf = fwd_w(w)
+    if c['bf3']:
+        hi = wf.to(torch.bfloat16)
+        kw.update(w_hi=hi, w_lo=(wf - hi.float()).to(torch.bfloat16))
+    if c['splits'] > 1:
+        ws = torch.empty(c['splits'] * N * Ho * Wo * Cout, device=DEV)
+        kw.update(splits=c['splits'], ws=ws, ws_floats=ws.numel())
+    y = torch.full((N, Ho, Wo, Cout), float('nan'), device=DEV)
+    try:
+        run_conv(nhwc(x), wf, y, K, sn=st, pad=K // 2, tile=c['tile'], bias=b.to(DEV), pro_act=c['act'], **kw)
+    except L.GaError as e:
+        assert 'UNSUPPORTED' in str(e) and c['tile'] in (5, 6), (c, str(e))
+        assert torch.isnan(y).all()
+        return
+    close(nchw(y), ref, 3e-4 if c['bf3'] else 3e-5, str(c))
+
+
 def test_conv_per_row_prologue():
     N, H, Cin, Cout = 4, 4, 16, 8
     x = g(N, Cin, H, H, seed=1)
