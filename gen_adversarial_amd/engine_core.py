@@ -1,0 +1,83 @@
+"""Shared pieces of the plan builder (engine.py and its per-network builder mixins): constants, the conv tuning
+table, the weight store and the activation record."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Optional
+
+import torch
+
+RES_SCALE = 0.1          # `0.1 * self.residual(x)` — architecture.py:133,183
+IMG_LD = 8                  # channel pitch of the NHWC image tensors (3 channels + zero padding)
+WS_FLOATS = 32 * 1024 * 1024     # split-K workspace shared by every conv of an engine (128 MB)
+TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
+_TUNE_CACHE: Optional[dict] = None
+
+
+def tune_cache() -> dict:
+    """(tile, splits) per conv shape, measured on an MI355X by Engine.autotune and kept in-tree."""
+    global _TUNE_CACHE
+    if _TUNE_CACHE is None:
+        _TUNE_CACHE = {}
+        if os.path.exists(TUNE_FILE):
+            with open(TUNE_FILE) as f:
+                _TUNE_CACHE = json.load(f)
+    return _TUNE_CACHE
+
+
+def conv_key(d) -> str:
+    return ('b3_' if d.w_hi else '') + '_'.join(str(int(v)) for v in (
+        d.N * d.Ho * d.Wo, d.Cout, d.C1, d.C2, d.KH, d.sn, d.sd, d.Hi, d.pro_act, bool(d.pro_scale), d.pro_per_row,
+        bool(d.dact_x), d.dact_act, bool(d.addend), bool(d.addend2), d.addend_bcast_n)) + (
+        f'_kw{d.KW}' if d.KW != d.KH else '')
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class WeightStore:
+    """Folded weights on the device, shared by every engine (row count) built for one model."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cache: Dict[str, dict] = {}
+        self.splits: Dict[int, tuple] = {}
+        self.bytes = 0
+
+    def split(self, w: torch.Tensor):
+        """bf16 (hi, lo) pair of a device weight tensor, hi = bf16(w), lo = bf16(w - hi); made once per tensor."""
+        k = w.data_ptr()
+        if k not in self.splits:
+            hi = w.to(torch.bfloat16)
+            lo = (w - hi.float()).to(torch.bfloat16)
+            self.splits[k] = (hi.contiguous(), lo.contiguous(), w)
+            self.bytes += 4 * w.numel()
+        return self.splits[k][0], self.splits[k][1]
+
+    def get(self, key: str, fn):
+        if key not in self.cache:
+            d = {k: v.to(self.device, dtype=torch.float32).contiguous() for k, v in fn().items()}
+            self.bytes += sum(v.numel() * 4 for v in d.values())
+            self.cache[key] = d
+        return self.cache[key]
+
+
+class Act:
+    """An NHWC activation buffer plus its (lazily allocated) gradient buffer."""
+
+    def __init__(self, eng: "Engine", n, h, w, c, name=''):
+        self.eng, self.n, self.h, self.w, self.c, self.name = eng, n, h, w, c, name
+        self.t = eng.alloc((n, h, w, c))
+        self._g = None
+        self.g_written = False
+        eng.acts[name] = self
+
+    @property
+    def g(self) -> torch.Tensor:
+        if self._g is None:
+            self._g = self.eng.alloc((self.n, self.h, self.w, self.c))
+        return self._g
+
+
