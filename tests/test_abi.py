@@ -31,7 +31,10 @@ def test_bad_descriptors_are_rejected_without_a_gpu():
     for desc, fn in ((L.ConvDesc(), L.lib.ga_conv2d), (L.DwDesc(), L.lib.ga_dwconv5), (L.ReduceDesc(), L.lib.ga_rowchan_reduce),
                      (L.SeExciteDesc(), L.lib.ga_se_excite), (L.SeApplyDesc(), L.lib.ga_se_apply),
                      (L.BilinearBwdDesc(), L.lib.ga_bilinear_up2_bwd), (L.SamplerDesc(), L.lib.ga_sampler_mix),
-                     (L.DmlDesc(), L.lib.ga_dml_mean), (L.MaxpoolDesc(), L.lib.ga_maxpool2), (L.ImageIoDesc(), L.lib.ga_image_io)):
+                     (L.DmlDesc(), L.lib.ga_dml_mean), (L.MaxpoolDesc(), L.lib.ga_maxpool2), (L.ImageIoDesc(), L.lib.ga_image_io),
+                     (L.BlurDesc(), L.lib.ga_gauss_blur), (L.Interleave2Desc(), L.lib.ga_interleave2),
+                     (L.Maxpool3s2Desc(), L.lib.ga_maxpool3s2), (L.AvgpoolActDesc(), L.lib.ga_avgpool_act),
+                     (L.GconvDesc(), L.lib.ga_gconv), (L.PreluDesc(), L.lib.ga_prelu)):
         assert fn(C.byref(desc), None) == -1
     assert L.lib.ga_plan_run(None, 0, None, None) == -1
     d = L.DwDesc()
