@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) se_apply_kernel(const ga_se_apply_desc d,
         const floatx4 g = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
         floatx4 s;
         if (d.skip_mode == 0) {
-            s = *reinterpret_cast<const floatx4*>(d.skip + i * 4);
+            s = d.skip ? *reinterpret_cast<const floatx4*>(d.skip + i * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
         } else if (d.skip_mode == 2) {
             s = *reinterpret_cast<const floatx4*>(d.skip + (((size_t)n * 2 * d.H + 2 * h) * 2 * d.W + 2 * w) * d.C + c);
         } else {
@@ -460,6 +460,46 @@ __global__ void __launch_bounds__(256) maxpool3s2_kernel(const ga_maxpool3s2_des
                     for (int e = 0; e < 4; ++e) if (win & (1u << e)) g[e] += dy[e];
                 }
             *reinterpret_cast<floatx4*>(d.dx + i * 4) = g;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// StyleGAN2 modulated conv pieces: small maps on the style / demodulation vectors, and the StyledConv tail
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) unary_kernel(const ga_unary_desc d) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) {
+        const float x = d.x[i];
+        float y;
+        switch (d.mode) {
+            case 0: y = x * x; break;
+            case 1: y = 2.0f * x * d.g[i]; break;
+            case 2: y = rsqrtf(x + d.eps); break;
+            default: y = -0.5f * d.g[i] * x * x; break;
+        }
+        d.y[i] = y;
+    }
+}
+
+__global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, const long total4) {
+    const int C4 = d.C / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4); const long r = i / C4;
+        const int p = (int)(r % d.P); const long n = r / d.P;
+        floatx4 sc = {1.f, 1.f, 1.f, 1.f}, ad = {0.f, 0.f, 0.f, 0.f};
+        if (d.scale) sc = ld4(d.scale + n * d.C + 4 * q);
+        if (d.add) ad = ld4(d.add + (size_t)p * d.C + 4 * q);
+        const floatx4 u = sc * ld4(d.t + i * 4) + ad;
+        floatx4 o;
+        if (!d.backward) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = act_fwd(u[e], d.act);
+            *reinterpret_cast<floatx4*>(d.out + i * 4) = o;
+        } else {
+            const floatx4 g = ld4(d.dout + i * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = g[e] * act_bwd(u[e], d.act) * sc[e];
+            *reinterpret_cast<floatx4*>(d.dt + i * 4) = o;
         }
     }
 }
@@ -808,11 +848,12 @@ extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
 
 extern "C" int ga_se_apply(const ga_se_apply_desc* d, void* s) {
     ga::clear_stale_error();
-    if (!d || !d->skip || !d->t || !d->gate || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (!d || !d->t || !d->gate || !d->out || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (!d->skip && d->skip_mode != 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (d->skip_mode == 1 && ((d->H | d->W) & 1)) return GA_E_BADARG;
     if (d->skip_mode < 0 || d->skip_mode > 2) return GA_E_UNSUPPORTED;
-    if (!aligned16(d->skip) || !aligned16(d->t) || !aligned16(d->gate) || !aligned16(d->out)) return GA_E_ALIGN;
+    if ((d->skip && !aligned16(d->skip)) || !aligned16(d->t) || !aligned16(d->gate) || !aligned16(d->out)) return GA_E_ALIGN;
     const long total4 = (long)d->N * d->H * d->W * (d->C / 4);
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
@@ -876,6 +917,25 @@ extern "C" int ga_maxpool3s2(const ga_maxpool3s2_desc* d, void* s) {
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
     const long total4 = d->backward ? (long)d->N * d->H * d->W * (d->C / 4) : (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
     hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_unary(const ga_unary_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->x || !d->y || d->n <= 0 || d->mode < 0 || d->mode > 3) return GA_E_BADARG;
+    if ((d->mode == 1 || d->mode == 3) && !d->g) return GA_E_BADARG;
+    hipLaunchKernelGGL(unary_kernel, dim3(grid_for(d->n)), dim3(256), 0, (hipStream_t)s, *d);
+    return check_launch();
+}
+
+extern "C" int ga_modout(const ga_modout_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->t || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && !d->out) return GA_E_BADARG;
+    if (d->backward && (!d->dout || !d->dt)) return GA_E_BADARG;
+    const long total4 = (long)d->N * d->P * (d->C / 4);
+    hipLaunchKernelGGL(modout_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }
 

@@ -19,6 +19,7 @@ __device__ __forceinline__ float act_fwd(float u, int act) {
         case GA_ACT_ELU:  return u > 0.0f ? u : expm1f(u);
         case GA_ACT_RELU: return fmaxf(u, 0.0f);
         case GA_ACT_LRELU: return u > 0.0f ? u : 0.01f * u;
+        case GA_ACT_FLRELU: return (u > 0.0f ? u : 0.2f * u) * 1.41421356237309515f;
         default:          return u;
     }
 }
@@ -30,6 +31,7 @@ __device__ __forceinline__ float act_bwd(float u, int act) {
         case GA_ACT_ELU:  return u > 0.0f ? 1.0f : expf(u);
         case GA_ACT_RELU: return u > 0.0f ? 1.0f : 0.0f;
         case GA_ACT_LRELU: return u > 0.0f ? 1.0f : 0.01f;
+        case GA_ACT_FLRELU: return (u > 0.0f ? 1.0f : 0.2f) * 1.41421356237309515f;
         default:          return 1.0f;
     }
 }

@@ -23,6 +23,8 @@ static int run_one(const ga_op& op, void* stream) {
         case GA_OP_AVGPOOL_ACT:  return ga_avgpool_act(&op.u.ap, stream);
         case GA_OP_GCONV:        return ga_gconv(&op.u.gc, stream);
         case GA_OP_PRELU:        return ga_prelu(&op.u.pr, stream);
+        case GA_OP_UNARY:        return ga_unary(&op.u.un, stream);
+        case GA_OP_MODOUT:       return ga_modout(&op.u.mo, stream);
         case GA_OP_AXPBY:        return ga_axpby(op.u.ax.x, op.u.ax.y, op.u.ax.n, op.u.ax.alpha, op.u.ax.beta, stream);
         default:                 return GA_E_UNSUPPORTED;
     }

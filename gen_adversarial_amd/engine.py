@@ -30,9 +30,10 @@ from .engine_core import (IMG_LD, RES_SCALE, TUNE_FILE, WS_FLOATS, Act, WeightSt
 from .engine_classifiers import ClassifierBuilder
 from .engine_e4e import E4EBuilder
 from .engine_nvae import NvaeBuilder
+from .engine_stylegan import StyleGanBuilder
 
 
-class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder):
+class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
@@ -76,6 +77,29 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder):
         self.bwd = L.Plan()
         self._bwd_steps = []                 # closures emitting backward ops, replayed in reverse
         self._build(nvae_sd, vgg_sd)
+
+    @classmethod
+    def bare(cls, rows: int, device='cuda:0', precision: str = 'bf16x3', store: Optional[WeightStore] = None,
+             dry_run: bool = False) -> "Engine":
+        """An engine with empty plans: building blocks that are not yet part of a full defender (the StyleGAN2 layers of
+        engine_stylegan.py) are emitted into it by their builders and closed with `finish()`; forward() / backward() then
+        replay the plans as for a full engine."""
+        self = cls.__new__(cls)
+        self.device, self.dry_run, self.precision = torch.device(device), dry_run, precision
+        if self.device.type != 'cuda' and not dry_run:
+            raise RuntimeError('the HIP engine needs a GPU device; there is no CPU fallback')
+        self.store = store if store is not None else WeightStore(self.device)
+        self.has_nvae, self.spec, self.vspec, self.resolution = False, None, None, None
+        self.rows, self.rep, self.alphas, self.temperature, self.noise_eps, self.blur = rows, 1, [], 1.0, 0.0, False
+        self.share_encoder, self.enc_rows, self.need_backward = False, rows, True
+        self.bytes, self.acts, self.version, self._sampler_descs, self._keep = 0, {}, 0, [], []
+        self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
+        self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
+        return self
+
+    def finish(self):
+        self._finish(0)
+        return self
 
     # ------------------------------------------------------------------------------------------------ memory
     def alloc(self, shape) -> torch.Tensor:
@@ -290,6 +314,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder):
                  self._build_e4e if isinstance(self.vspec, E4ESpec) else self._build_vgg)
         self.logits = build(vgg_sd, img)
 
+        self._finish(n_nvae_steps)
+
+    def _finish(self, n_nvae_steps: int = 0):
         # ---- emit the backward plan: reverse registration order (classifier part first)
         self.bwd_split = 0
         if self.need_backward:

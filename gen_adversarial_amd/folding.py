@@ -360,3 +360,40 @@ def fold_e4e_style(sd: SD, j: int, pools: int) -> dict:
     wl = wl * (1.0 / (wl.shape[1] ** 0.5))
     out['wl'], out['wl_bwd'], out['bl'] = f32(wl), f32(wl.t()), f32(sd[f'styles.{j}.linear.bias'])
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# StyleGAN2 modulated convolution (StyleGan_E4E/stylegan2/generator.py:108-207)
+# ------------------------------------------------------------------------------------------------------------------
+def fold_styled_conv(sd: SD, spec, noise: torch.Tensor = None, cout_pad: int = 0) -> dict:
+    """ModulatedConv2d without resampling, rewritten so that the per-sample weights never exist:
+        weight[n] = scale * W * s[n, ci] * demod[n, co]   (generator.py:166-176)
+      ==> out[n] = demod[n] * conv(scale * W, x[n] * s[n]),   demod[n, co] = rsqrt(sum_ci W2[co, ci] s[n, ci]^2 + 1e-8)
+    with W2 = scale^2 * sum_taps W^2.  Returns the shared conv weights (forward / backward layouts), W2 (both layouts), the
+    modulation EqualLinear (lr_mul = 1: weight / sqrt(D), bias as is; generator.py:85-98) and the row-independent additive
+    term of the layer's tail: noise.weight * noise[p] + activate.bias[c] (StyledConv, generator.py:258-265, fixed noise
+    buffers) or ToRGB's bias (generator.py:282-283).  cout_pad > 0 pads Cout with zero filters (ToRGB: 3 -> 4 lanes)."""
+    p = spec.prefix
+    w = sd[f'{p}.conv.weight'][0].double()                           # [Cout, Cin, k, k]
+    w = w * (1.0 / (w.shape[1] * w.shape[2] * w.shape[3]) ** 0.5)
+    co = w.shape[0]
+    if cout_pad > co:
+        w = torch.cat([w, w.new_zeros(cout_pad - co, *w.shape[1:])], dim=0)
+    wm = sd[f'{p}.conv.modulation.weight'].double()
+    wm = wm * (1.0 / wm.shape[1] ** 0.5)
+    out = {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)),
+           'wm': f32(wm), 'wm_bwd': f32(wm.t()), 'bm': f32(sd[f'{p}.conv.modulation.bias'])}
+    if spec.demodulate:
+        w2 = w.pow(2).sum(dim=(2, 3))                                # [Cout, Cin]
+        out['w2'], out['w2_bwd'] = f32(w2), f32(w2.t())
+    P = spec.res * spec.res
+    if spec.activate:
+        add = sd[f'{p}.activate.bias'].double().view(1, -1).expand(P, -1).clone()
+        if noise is not None:
+            add = add + sd[f'{p}.noise.weight'].double() * noise.double().reshape(P, 1)
+    else:
+        add = sd[f'{p}.bias'].double().view(1, -1).expand(P, -1).clone()
+    if cout_pad > co:
+        add = torch.cat([add, add.new_zeros(P, cout_pad - co)], dim=1)
+    out['add'] = f32(add)
+    return out

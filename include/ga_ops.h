@@ -30,7 +30,9 @@ extern "C" {
 #define GA_E_LAUNCH     -4   /* hipLaunch failed (see ga_last_hip_error) */
 
 enum ga_act { GA_ACT_NONE = 0, GA_ACT_SILU = 1, GA_ACT_ELU = 2, GA_ACT_RELU = 3,
-              GA_ACT_LRELU = 4 /* nn.LeakyReLU(): slope 0.01 (GradualStyleBlock, encoding/encoder.py:41-46) */ };
+              GA_ACT_LRELU = 4 /* nn.LeakyReLU(): slope 0.01 (GradualStyleBlock, encoding/encoder.py:41-46) */,
+              GA_ACT_FLRELU = 5 /* fused_leaky_relu without its bias: leaky_relu(x, 0.2) * sqrt(2) (stylegan2/op/fused_act.py:80-85,
+                                   fused_bias_act_kernel.cu:18-49); elementwise passes only, not a conv prologue */ };
 /* ga_conv_desc.flags — residual networks that keep PRE-activation sums (torchvision Bottleneck: out = relu(f(x) + identity)):
  *   GA_CONV_ADDEND_RELU     forward : y = ... + relu(addend)            (the identity branch is relu of the stored pre-activation)
  *   GA_CONV_ADDEND_PRE_DACT backward: y = (acc + addend) * act'(dact_x) (+ addend2): the identity branch's cotangent passes
@@ -143,7 +145,7 @@ typedef struct ga_se_excite_desc {
 } ga_se_excite_desc;
 int ga_se_excite(const ga_se_excite_desc* d, void* stream);
 
-/* out[n,h,w,c] = skip(n,h,w,c) + res_scale * gate[n,c] * t[n,h,w,c]
+/* out[n,h,w,c] = skip(n,h,w,c) + res_scale * gate[n,c] * t[n,h,w,c]      (skip may be NULL with skip_mode 0: a pure row-scale)
  * skip_mode 0: skip is [N,H,W,C]; 1: skip is [N,H/2,W/2,C] read through bilinear x2, align_corners=True;
  * 2: skip is [N,2H,2W,C] sub-sampled at the even pixels (MaxPool2d(1, 2) shortcut of bottleneck_IR_SE, helpers.py:100-101)
  * (SkipUp, architecture.py:91-93; the 1x1 conv commutes with the interpolation and is applied at low resolution). */
@@ -222,6 +224,28 @@ typedef struct ga_gconv_desc {
     int _reserved;
 } ga_gconv_desc;
 int ga_gconv(const ga_gconv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * StyleGAN2 modulated convolution (stylegan2/generator.py:108-207) = ga_conv2d with the per-(row, channel) prologue scale
+ * (style) + the pieces below.  With W the shared weights (scaled by 1/sqrt(fan_in)), s[n,ci] the style:
+ *   t = conv(W, x * s);  demod[n,co] = rsqrt(sum_ci W2[co,ci] s[n,ci]^2 + 1e-8),  W2 = sum_taps W^2;  y = demod * t
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* small per-(row, channel) maps on [n] floats:
+ *   mode 0  y = x^2                         mode 1  y = 2 x g                (backward of 0: g = d/dy, x the forward input)
+ *   mode 2  y = rsqrt(x + eps)              mode 3  y = -0.5 g x^2           (x = the forward OUTPUT demod, g = sum_p dt*t:
+ *                                                    d/d(sum W2 s^2) of the loss when g is taken w.r.t. demod*... see DESIGN) */
+typedef struct ga_unary_desc { const float* x; const float* g; float* y; long n; int mode; float eps; } ga_unary_desc;
+int ga_unary(const ga_unary_desc* d, void* stream);
+
+/* StyledConv's tail (generator.py:258-265: demodulation folded out of the weights, NoiseInjection, FusedLeakyReLU):
+ *   forward : out[n,p,c] = act(u),  u = scale[n,c] * t[n,p,c] + add[p,c]        (scale / add may be NULL = 1 / 0)
+ *   backward: dt[n,p,c]  = dout * act'(u) * scale[n,c]                          (u recomputed from t)
+ * t, out, dout, dt: [N,P,C]; scale: [N,C]; add: [P,C] (noise strength * noise[p] + bias[c], row independent). C % 4 == 0. */
+typedef struct ga_modout_desc {
+    const float* t; const float* scale; const float* add; float* out; const float* dout; float* dt;
+    int N, P, C; int act; int backward; int _reserved;
+} ga_modout_desc;
+int ga_modout(const ga_modout_desc* d, void* stream);
 
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
@@ -310,7 +334,8 @@ int ga_axpby(const float* x, float* y, long n, float alpha, float beta, void* st
 enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_EXCITE = 4, GA_OP_SE_APPLY = 5,
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
-                  GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18 };
+                  GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
+                  GA_OP_MODOUT = 20 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -321,6 +346,7 @@ typedef struct ga_op {
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
+        ga_unary_desc un; ga_modout_desc mo;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -242,3 +242,23 @@ def test_batched_evaluation_equals_the_one_image_protocol():
     many = evaluate_shard(net, attacks, x, y, batch_images=3)
     torch.testing.assert_close(many, one, rtol=0, atol=1e-6)
     assert one[2, 0] == 0 and one[:, 0].sum() == 6
+
+
+def test_styled_conv_plans_build_without_a_gpu():
+    """the StyleGAN2 modulated-conv builder (engine_stylegan.py) emits well-formed forward / backward plans"""
+    from gen_adversarial_amd import _lib as L
+    from gen_adversarial_amd.engine_core import Act
+    from gen_adversarial_amd.stylegan_spec import StyledConvSpec, init_styled_conv_state_dict
+    sp = StyledConvSpec('conv1', 32, 64, 3, 64, 8, True, True)
+    rgb = StyledConvSpec('to_rgb1', 64, 3, 1, 64, 8, False, False)
+    eng = Engine.bare(2, device='cpu', dry_run=True)
+    x, w = Act(eng, 2, 8, 8, 32, 'x'), Act(eng, 2, 1, 1, 64, 'w')
+    h = eng.styled_conv(init_styled_conv_state_dict(sp, 1), sp, x, w, noise=torch.randn(8, 8))
+    img = eng.styled_conv(init_styled_conv_state_dict(rgb, 2), rgb, h, w)
+    eng.finish()
+    assert (img.c, h.c) == (4, 64)
+    kinds = [type(d).__name__ for d in eng.fwd.descs]
+    assert kinds.count('ConvDesc') == 5 and kinds.count('ModoutDesc') == 2 and kinds.count('UnaryDesc') == 2
+    # backward: the latent gradient is written by the last layer's modulation^T and accumulated by the first one's
+    mods = [d for d, n in zip(eng.bwd.descs, eng.bwd.names) if n.endswith('modulation^T')]
+    assert len(mods) == 2 and not mods[0].addend and mods[1].addend

@@ -3,6 +3,7 @@ CPU: the oracle (our restatement) against golden vectors produced by the referen
 (tests/golden/make_golden.py).  Tolerance 1e-5 as stated in BASELINE.md §3.
 """
 import ast
+import os
 
 import numpy as np
 import pytest
@@ -137,3 +138,23 @@ def test_e4e_oracle_matches_the_reference_encoder():
     (gx,) = torch.autograd.grad((w * torch.from_numpy(g['cot'])).sum(), [x])
     assert (w.detach() - torch.from_numpy(g['w'])).abs().max().item() < 1e-5
     assert (gx - torch.from_numpy(g['gx'])).abs().max().item() < 1e-5 * max(1.0, float(np.abs(g['gx']).max()))
+
+
+def test_stylegan_modulated_conv_oracle_matches_the_reference():
+    """oracle/stylegan_oracle.py against the reference's ModulatedConv2d (tests/golden/make_stylegan_golden.py): output,
+    d/dx and d/dstyle of the demodulated 3x3 conv (StyledConv) and of the plain 1x1 conv (ToRGB)"""
+    from oracle.stylegan_oracle import modulated_conv
+    from gen_adversarial_amd.stylegan_spec import StyledConvSpec, init_styled_conv_state_dict
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'stylegan_modconv.npz'))
+    cases = {'styled': StyledConvSpec('conv1', 32, 64, 3, 64, 8, True, True),
+             'torgb': StyledConvSpec('to_rgb1', 64, 3, 1, 64, 8, False, False)}
+    for name, sp in cases.items():
+        sd = init_styled_conv_state_dict(sp, int(g['seed']))
+        x = torch.from_numpy(g[f'{name}.x']).requires_grad_(True)
+        w = torch.from_numpy(g[f'{name}.w']).requires_grad_(True)
+        y = modulated_conv(x, w, sd[f'{sp.prefix}.conv.weight'], sd[f'{sp.prefix}.conv.modulation.weight'],
+                           sd[f'{sp.prefix}.conv.modulation.bias'], sp.demodulate)
+        gx, gw = torch.autograd.grad((y * torch.from_numpy(g[f'{name}.cot'])).sum(), [x, w])
+        for got, key in ((y, 'y'), (gx, 'gx'), (gw, 'gw')):
+            ref = torch.from_numpy(g[f'{name}.{key}'])
+            assert (got.detach() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), (name, key)
