@@ -22,7 +22,7 @@ GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU, GA_ACT_LRELU, GA_ACT_FLRELU =
 GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PRELU = 1, 2, 4, 8
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
  GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR, GA_OP_REP_SUM, GA_OP_INTERLEAVE2,
- GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT) = range(1, 21)
+ GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR) = range(1, 22)
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -141,11 +141,16 @@ class ModoutDesc(C.Structure):
                 ('N', i32), ('P', i32), ('C', i32), ('act', i32), ('backward', i32), ('_reserved', i32)]
 
 
+class Up2BlurDesc(C.Structure):
+    _fields_ = [('lo_in', fp), ('hi', fp), ('hi_in', fp), ('lo', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32),
+                ('backward', i32), ('_reserved', i32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [('conv', ConvDesc), ('dw', DwDesc), ('red', ReduceDesc), ('se', SeExciteDesc), ('app', SeApplyDesc),
                 ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
                 ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc), ('rs', RepSumDesc), ('il', Interleave2Desc),
-                ('mp3', Maxpool3s2Desc), ('ap', AvgpoolActDesc), ('gc', GconvDesc), ('pr', PreluDesc), ('un', UnaryDesc), ('mo', ModoutDesc)]
+                ('mp3', Maxpool3s2Desc), ('ap', AvgpoolActDesc), ('gc', GconvDesc), ('pr', PreluDesc), ('un', UnaryDesc), ('mo', ModoutDesc), ('ub', Up2BlurDesc)]
 
 
 class Op(C.Structure):
@@ -155,17 +160,17 @@ class Op(C.Structure):
 _KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_OP_SE_EXCITE: 'se',
                GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
                GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur', GA_OP_REP_SUM: 'rs',
-               GA_OP_INTERLEAVE2: 'il', GA_OP_MAXPOOL3S2: 'mp3', GA_OP_AVGPOOL_ACT: 'ap', GA_OP_GCONV: 'gc', GA_OP_PRELU: 'pr', GA_OP_UNARY: 'un', GA_OP_MODOUT: 'mo'}
+               GA_OP_INTERLEAVE2: 'il', GA_OP_MAXPOOL3S2: 'mp3', GA_OP_AVGPOOL_ACT: 'ap', GA_OP_GCONV: 'gc', GA_OP_PRELU: 'pr', GA_OP_UNARY: 'un', GA_OP_MODOUT: 'mo', GA_OP_UP2_BLUR: 'ub'}
 _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
               SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
               DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY,
               BlurDesc: GA_OP_BLUR, RepSumDesc: GA_OP_REP_SUM, Interleave2Desc: GA_OP_INTERLEAVE2,
               Maxpool3s2Desc: GA_OP_MAXPOOL3S2, AvgpoolActDesc: GA_OP_AVGPOOL_ACT, GconvDesc: GA_OP_GCONV,
-              PreluDesc: GA_OP_PRELU, UnaryDesc: GA_OP_UNARY, ModoutDesc: GA_OP_MODOUT}
+              PreluDesc: GA_OP_PRELU, UnaryDesc: GA_OP_UNARY, ModoutDesc: GA_OP_MODOUT, Up2BlurDesc: GA_OP_UP2_BLUR}
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -179,7 +184,7 @@ def _load():
                  ('ga_sampler_mix', SamplerDesc), ('ga_dml_mean', DmlDesc), ('ga_maxpool2', MaxpoolDesc),
                  ('ga_image_io', ImageIoDesc), ('ga_gauss_blur', BlurDesc), ('ga_interleave2', Interleave2Desc),
                  ('ga_maxpool3s2', Maxpool3s2Desc), ('ga_avgpool_act', AvgpoolActDesc), ('ga_gconv', GconvDesc), ('ga_prelu', PreluDesc),
-                 ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc)):
+                 ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc), ('ga_up2_blur', Up2BlurDesc)):
         f = getattr(lib, n)
         f.argtypes = [C.POINTER(d), C.c_void_p]
         f.restype = C.c_int
@@ -234,7 +239,7 @@ _DIRECT = {ConvDesc: 'ga_conv2d', DwDesc: 'ga_dwconv5', ReduceDesc: 'ga_rowchan_
            SeApplyDesc: 'ga_se_apply', BilinearBwdDesc: 'ga_bilinear_up2_bwd', SamplerDesc: 'ga_sampler_mix',
            DmlDesc: 'ga_dml_mean', MaxpoolDesc: 'ga_maxpool2', ImageIoDesc: 'ga_image_io', BlurDesc: 'ga_gauss_blur',
            Interleave2Desc: 'ga_interleave2', Maxpool3s2Desc: 'ga_maxpool3s2', AvgpoolActDesc: 'ga_avgpool_act',
-           GconvDesc: 'ga_gconv', PreluDesc: 'ga_prelu', UnaryDesc: 'ga_unary', ModoutDesc: 'ga_modout'}
+           GconvDesc: 'ga_gconv', PreluDesc: 'ga_prelu', UnaryDesc: 'ga_unary', ModoutDesc: 'ga_modout', Up2BlurDesc: 'ga_up2_blur'}
 
 
 def run(desc, stream: int = 0):

@@ -504,6 +504,51 @@ __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, con
     }
 }
 
+__global__ void __launch_bounds__(256) up2_blur_kernel(const ga_up2_blur_desc d, const long total4) {
+    const int C4 = d.C / 4;
+    const int Ho = d.backward ? d.H : 2 * d.H, Wo = d.backward ? d.W : 2 * d.W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % C4); long r = i / C4;
+        const int v = (int)(r % Wo); r /= Wo;
+        const int u = (int)(r % Ho); const long n = r / Ho;
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (!d.backward) {
+            // rows U0 / U0+1 with weights wy0 / wy1 (even u: U-1, U with 1/4, 3/4; odd u: U, U+1 with 3/4, 1/4)
+            const int U0 = (u >> 1) - 1 + (u & 1), V0 = (v >> 1) - 1 + (v & 1);
+            const float wy0 = (u & 1) ? 0.75f : 0.25f, wx0 = (v & 1) ? 0.75f : 0.25f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int U = U0 + a;
+                if (U < 0 || U >= d.H) continue;
+                const float wy = a ? 1.0f - wy0 : wy0;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int V = V0 + b;
+                    if (V < 0 || V >= d.W) continue;
+                    const float wgt = wy * (b ? 1.0f - wx0 : wx0);
+                    acc += wgt * ld4(d.lo_in + (((size_t)n * d.H + U) * d.W + V) * d.C + 4 * q);
+                }
+            }
+            float* o = d.hi + i * 4;
+            *reinterpret_cast<floatx4*>(o) = ld4(o) + acc;
+        } else {
+            const float k4[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int uu = 2 * u - 1 + a;
+                if (uu < 0 || uu >= 2 * d.H) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int vv = 2 * v - 1 + b;
+                    if (vv < 0 || vv >= 2 * d.W) continue;
+                    acc += (k4[a] * k4[b]) * ld4(d.hi_in + (((size_t)n * 2 * d.H + uu) * 2 * d.W + vv) * d.C + 4 * q);
+                }
+            }
+            *reinterpret_cast<floatx4*>(d.lo + i * 4) = acc;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // nn.PReLU as its own pass (forward / backward)
 // ---------------------------------------------------------------------------------------------------------------
@@ -936,6 +981,17 @@ extern "C" int ga_modout(const ga_modout_desc* d, void* s) {
     if (d->backward && (!d->dout || !d->dt)) return GA_E_BADARG;
     const long total4 = (long)d->N * d->P * (d->C / 4);
     hipLaunchKernelGGL(modout_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_up2_blur(const ga_up2_blur_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (d->C % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && (!d->lo_in || !d->hi)) return GA_E_BADARG;
+    if (d->backward && (!d->hi_in || !d->lo)) return GA_E_BADARG;
+    const long total4 = (long)d->N * d->H * d->W * (d->C / 4) * (d->backward ? 1 : 4);
+    hipLaunchKernelGGL(up2_blur_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }
 

@@ -1,6 +1,6 @@
 """
-Plan builder for the StyleGAN2 synthesis layers (StyleGan_E4E/stylegan2/generator.py): this round the modulated
-convolution without resampling — StyledConv(upsample=False) and ToRGB's convolution.
+Plan builder for the StyleGAN2 synthesis network (StyleGan_E4E/stylegan2/generator.py): StyledConv with and without
+up-sampling, ToRGB with its up-sampled skip, and Generator.forward's wiring for latent input and fixed noise buffers.
 
 The reference builds per-sample weights [N*Cout, Cin, k, k] and runs a grouped convolution (generator.py:166-203); here
 the weights stay shared: the style scales the INPUT channels in the conv's per-row prologue and the demodulation scales
@@ -16,6 +16,8 @@ the OUTPUT channels in the tail pass (folding.fold_styled_conv).  Forward / back
   ds     = 2 s W2^T d(W2 s^2) + sum_p dxm x     ga_conv2d 1x1, ga_unary, ga_rowchan_reduce, ga_axpby
   dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d, ga_se_apply (row scale, accumulating into x.g)
   dw_latent += modulation^T ds                  ga_conv2d 1x1
+Up-sampling layer: transposed conv + blur = one 6x6 / stride-2 transposed conv (folding.upsample_conv_weights): four 3x3
+parity convs + ga_interleave2 forward, one 6x6 / 2 conv backward.  ToRGB skip: ga_up2_blur.
 """
 from __future__ import annotations
 
@@ -27,23 +29,57 @@ from .engine_core import Act, _ptr
 from .stylegan_spec import StyledConvSpec
 
 
+class LatentSlice:
+    """latent[:, j] of a [N, n_latent, D] code tensor held in one Act [N,1,1,n_latent*D]: strided views + its own
+    written-flag (several layers read the same index: generator.py:452-461)"""
+
+    def __init__(self, latent: Act, j: int, dim: int):
+        self.n, self.c, self.ld = latent.n, dim, latent.c
+        self.t = latent.t.view(latent.n, 1, 1, latent.c)[..., j * dim:(j + 1) * dim]
+        self.g = latent.g.view(latent.n, 1, 1, latent.c)[..., j * dim:(j + 1) * dim]
+        self.g_written = False
+
+
 class StyleGanBuilder:
-    def styled_conv(self, sd, spec: StyledConvSpec, x: Act, w_latent: Act, noise: torch.Tensor = None) -> Act:
-        """emit one modulated convolution: x [N,res,res,Cin] (post-activation), w_latent [N,1,1,D] -> Act [N,res,res,Cout']
-        (Cout' = Cout rounded up to 4 lanes; padded lanes hold zeros).  Gradients flow to x.g and w_latent.g."""
+    def styled_conv(self, sd, spec: StyledConvSpec, x: Act, w_latent, noise: torch.Tensor = None, skip: Act = None,
+                    need_dx: bool = True) -> Act:
+        """emit one modulated convolution: x [N,r,r,Cin] (post-activation; r = res/2 for the up-sampling layer), w_latent an
+        Act [N,1,1,D] or a LatentSlice -> Act [N,res,res,Cout'] (Cout' = Cout rounded up to 4 lanes; padded lanes hold zeros).
+        skip: ToRGB's previous image at half the resolution (up-sampled and added).  Gradients flow to x.g, w_latent.g, skip.g."""
         R, p = self.rows, spec.prefix
-        assert (x.n, x.h, x.w, x.c) == (R, spec.res, spec.res, spec.cin) and (w_latent.n, w_latent.c) == (R, spec.style_dim)
+        rin = spec.res // 2 if spec.upsample else spec.res
+        assert (x.n, x.h, x.w, x.c) == (R, rin, rin, spec.cin) and (w_latent.n, w_latent.c) == (R, spec.style_dim), p
+        lat_ld = getattr(w_latent, 'ld', w_latent.c)
         co = -(-spec.cout // 4) * 4
         nkey = 'none' if noise is None else f'{noise.data_ptr():x}'
-        wts = self.devd(f'sg.{p}.{spec.res}.{nkey}', lambda: F.fold_styled_conv(sd, spec, noise, cout_pad=co))
-        P, k = spec.res * spec.res, spec.kernel
+
+        def fold():
+            f = F.fold_styled_conv(sd, spec, noise, cout_pad=co)
+            if spec.upsample:
+                f.update(F.upsample_conv_weights(f.pop('w64')))
+                f.pop('w'), f.pop('w_bwd')
+            f.pop('w64', None)
+            return f
+        wts = self.devd(f'sg.{p}.{spec.res}.{nkey}', fold)
+        P, Pin, k = spec.res * spec.res, rin * rin, spec.kernel
         act = L.GA_ACT_FLRELU if spec.activate else L.GA_ACT_NONE
 
         s = Act(self, R, 1, 1, spec.cin, f'{p}.style')
-        self.conv(self.fwd, f'{p}.modulation', w_latent.t, wts['wm'], s.t, bias=wts['bm'], K=1)
+        self.conv(self.fwd, f'{p}.modulation', w_latent.t, wts['wm'], s.t, bias=wts['bm'], K=1, ldx=lat_ld)
         zeros = self.devd(f'sg.zeros.{R}.{spec.cin}', lambda: {'z': torch.zeros(R, spec.cin)})['z']
+        pro = dict(pro_scale=s.t, pro_shift=zeros, pro_per_row=1)
         t = Act(self, R, spec.res, spec.res, co, f'{p}.t')
-        self.conv(self.fwd, f'{p}.conv', x.t, wts['w'], t.t, K=k, pad=k // 2, pro_scale=s.t, pro_shift=zeros, pro_per_row=1)
+        if spec.upsample:                                        # four parity convs over the low-resolution input
+            il = L.Interleave2Desc()
+            for a in (0, 1):
+                for b in (0, 1):
+                    plane = self.scratch((R, rin, rin, co), f'sg.up{a}{b}')
+                    self.conv(self.fwd, f'{p}.conv[{a}{b}]', x.t, wts[f'up{a}{b}'], plane, K=3, pad=1, **pro)
+                    il.s[2 * a + b] = _ptr(plane)
+            il.y, il.N, il.H, il.W, il.C = _ptr(t.t), R, spec.res, spec.res, co
+            self.fwd.add(il, f'{p}.conv.interleave')
+        else:
+            self.conv(self.fwd, f'{p}.conv', x.t, wts['w'], t.t, K=k, pad=k // 2, **pro)
         demod = None
         if spec.demodulate:
             s2 = self.alloc((R, 1, 1, spec.cin))
@@ -57,16 +93,30 @@ class StyleGanBuilder:
         m.t, m.scale, m.add, m.out = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.t)
         m.N, m.P, m.C, m.act, m.backward = R, P, co, act, 0
         self.fwd.add(m, f'{p}.tail')
+        if skip is not None:
+            assert (skip.n, skip.h, skip.w, skip.c) == (R, spec.res // 2, spec.res // 2, co), p
+            u = L.Up2BlurDesc()
+            u.lo_in, u.hi, u.N, u.H, u.W, u.C, u.backward = _ptr(skip.t), _ptr(out.t), R, skip.h, skip.w, co, 0
+            self.fwd.add(u, f'{p}.skip_upsample')
 
         def backward():
+            if skip is not None:
+                assert not skip.g_written
+                ub = L.Up2BlurDesc()
+                ub.hi_in, ub.lo, ub.N, ub.H, ub.W, ub.C, ub.backward = _ptr(out.g), _ptr(skip.g), R, skip.h, skip.w, co, 1
+                self.bwd.add(ub, f'{p}.skip_upsample^T')
+                skip.g_written = True
             b = L.ModoutDesc()
             b.t, b.scale, b.add, b.dout, b.dt = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.g), _ptr(t.g)
             b.N, b.P, b.C, b.act, b.backward = R, P, co, act, 1
             self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
-            dxm = self.scratch((R, spec.res, spec.res, spec.cin), 'sg.dxm')
-            self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
-            self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, P, spec.cin)
+            dxm = self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
+            if spec.upsample:                                    # adjoint of (transposed conv + blur): one 6x6 / 2 conv
+                self.conv(self.bwd, f'{p}.conv^T', t.g, wts['up_bwd'], dxm, K=6, sn=2, pad=2)
+            else:
+                self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
+            self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, Pin, spec.cin)
             if spec.demodulate:
                 gq = self.scratch((R, 1, 1, co), 'sg.gq')
                 ds2 = self.scratch((R, 1, 1, spec.cin), 'sg.ds2')
@@ -77,15 +127,38 @@ class StyleGanBuilder:
                 a = L.AxpbyDesc()
                 a.x, a.y, a.n, a.alpha, a.beta = _ptr(ds2), _ptr(ds), R * spec.cin, 1.0, 1.0
                 self.bwd.add(a, f'{p}.dstyle_sum')
-            self.grad_conv(f'{p}.modulation^T', ds, wts['wm_bwd'], w_latent, K=1)
-            ap = L.SeApplyDesc()                                 # dx = dxm * s (+ an already written x.g)
-            ap.skip = _ptr(x.g) if x.g_written else None
-            ap.t, ap.gate, ap.out = _ptr(dxm), _ptr(s.t), _ptr(x.g)
-            ap.N, ap.H, ap.W, ap.C, ap.skip_mode, ap.res_scale = R, spec.res, spec.res, spec.cin, 0, 1.0
-            self.bwd.add(ap, f'{p}.dx')
-            x.g_written = True
+            self.conv(self.bwd, f'{p}.modulation^T', ds, wts['wm_bwd'], w_latent.g, K=1, ldy=lat_ld,
+                      addend=(w_latent.g if w_latent.g_written else None), ldadd=lat_ld)
+            w_latent.g_written = True
+            if need_dx:
+                ap = L.SeApplyDesc()                             # dx = dxm * s (+ an already written x.g)
+                ap.skip = _ptr(x.g) if x.g_written else None
+                ap.t, ap.gate, ap.out = _ptr(dxm), _ptr(s.t), _ptr(x.g)
+                ap.N, ap.H, ap.W, ap.C, ap.skip_mode, ap.res_scale = R, rin, rin, spec.cin, 0, 1.0
+                self.bwd.add(ap, f'{p}.dx')
+                x.g_written = True
         self._bwd_steps.append(backward)
         return out
+
+    def build_stylegan(self, sd, spec, latent: Act) -> Act:
+        """The synthesis network for styles=[latent], input_is_latent=True, randomize_noise=False (generator.py:399-470):
+        latent Act [N,1,1,n_latent*D] -> image Act [N,size,size,4] (lane 3 is zero).  latent.g receives the gradient."""
+        R, D = self.rows, spec.style_dim
+        assert latent.c == spec.n_latent * D and latent.n == R
+        lat = [LatentSlice(latent, j, D) for j in range(spec.n_latent)]
+        noise = [sd[f'noises.noise_{i}'][0, 0] for i in range(1 + len(spec.convs))]
+        const = Act(self, R, 4, 4, spec.const_channels, 'sg.const')          # ConstantInput (generator.py:214-224)
+        const.t.copy_(sd['input.input'].permute(0, 2, 3, 1).expand(R, -1, -1, -1))
+        out = self.styled_conv(sd, spec.conv1, const, lat[0], noise[0], need_dx=False)
+        img = self.styled_conv(sd, spec.to_rgb1, out, lat[1])
+        i = 1
+        for k in range(len(spec.to_rgbs)):
+            out = self.styled_conv(sd, spec.convs[2 * k], out, lat[i], noise[1 + 2 * k])
+            out = self.styled_conv(sd, spec.convs[2 * k + 1], out, lat[i + 1], noise[2 + 2 * k])
+            img = self.styled_conv(sd, spec.to_rgbs[k], out, lat[i + 2], skip=img)
+            i += 2
+        latent.g_written = True
+        return img
 
     def _unary(self, plan, name, mode, x, g, y, eps=0.0):
         u = L.UnaryDesc()

@@ -381,7 +381,7 @@ def fold_styled_conv(sd: SD, spec, noise: torch.Tensor = None, cout_pad: int = 0
         w = torch.cat([w, w.new_zeros(cout_pad - co, *w.shape[1:])], dim=0)
     wm = sd[f'{p}.conv.modulation.weight'].double()
     wm = wm * (1.0 / wm.shape[1] ** 0.5)
-    out = {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)),
+    out = {'w': f32(conv_fwd_layout(w)), 'w_bwd': f32(conv_bwd_layout(w)), 'w64': w,
            'wm': f32(wm), 'wm_bwd': f32(wm.t()), 'bm': f32(sd[f'{p}.conv.modulation.bias'])}
     if spec.demodulate:
         w2 = w.pow(2).sum(dim=(2, 3))                                # [Cout, Cin]
@@ -396,4 +396,33 @@ def fold_styled_conv(sd: SD, spec, noise: torch.Tensor = None, cout_pad: int = 0
     if cout_pad > co:
         add = torch.cat([add, add.new_zeros(P, cout_pad - co)], dim=1)
     out['add'] = f32(add)
+    return out
+
+
+def upsample_conv_weights(w: torch.Tensor) -> dict:
+    """StyledConv(upsample=True): conv_transpose2d(stride 2, no padding) followed by the [1,3,3,1] (x4) blur with pad (1, 1)
+    (generator.py:133-139,178-189) is ONE linear map: a stride-2 transposed convolution with the 6x6 kernel
+        G[d, e] = sum_{i,j} W[i, j] K[i + 1 - d, j + 1 - e],   d, e in [-2, 3]      (K = outer(k, k) / 16, k = [1,3,3,1])
+        out[2U+a, 2V+b] = sum_{dy,dx in {-1,0,1}} z[U+dy, V+dx] G[a - 2 dy, b - 2 dx]
+    i.e. four ordinary 3x3 / pad 1 convolutions over the low-resolution input, one per output parity (a, b), and — for the
+    backward-to-input — one 6x6 / stride 2 / pad 2 convolution over the high-resolution cotangent.
+    w: [Cout, Cin, 3, 3] (already scaled).  Returns {'up{a}{b}': [Cout][9*Cin], 'up_bwd': [Cin][36*Cout]}."""
+    co, ci = w.shape[:2]
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=torch.float64)
+    K = torch.outer(k1, k1) / 16.0
+    G = w.new_zeros(co, ci, 6, 6)                                   # index = d + 2
+    for i in range(3):
+        for j in range(3):
+            for a in range(4):
+                for b in range(4):
+                    G[:, :, i + 1 - a + 2, j + 1 - b + 2] += w[:, :, i, j] * K[a, b]
+    out = {}
+    for a in (0, 1):
+        for b in (0, 1):
+            wp = w.new_zeros(co, ci, 3, 3)
+            for ky in range(3):
+                for kx in range(3):
+                    wp[:, :, ky, kx] = G[:, :, a - 2 * (ky - 1) + 2, b - 2 * (kx - 1) + 2]
+            out[f'up{a}{b}'] = f32(conv_fwd_layout(wp))
+    out['up_bwd'] = f32(conv_fwd_layout(G.permute(1, 0, 2, 3)))
     return out

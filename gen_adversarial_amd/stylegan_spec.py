@@ -1,9 +1,10 @@
 """
 Parameter layout of the StyleGAN2 synthesis layers the e4e defender decodes with
-(src/mlvgms_autoencoders/StyleGan_E4E/stylegan2/generator.py).  This round covers ONE layer family: the modulated
-convolution without resampling — `StyledConv(upsample=False)` (generator.py:229-265: ModulatedConv2d, NoiseInjection,
-FusedLeakyReLU) and the `ToRGB` convolution (generator.py:268-290, demodulate=False, 1x1, plain bias).  The upsampling
-variant (transposed conv + blur), the mapping MLP and the generator's wiring are the next rows.
+(src/mlvgms_autoencoders/StyleGan_E4E/stylegan2/generator.py): `StyledConv` with and without up-sampling
+(generator.py:229-265: ModulatedConv2d, NoiseInjection, FusedLeakyReLU), `ToRGB` (generator.py:268-290: 1x1 modulated conv
+without demodulation, bias, up-sampled skip) and the synthesis network's wiring for `input_is_latent=True,
+randomize_noise=False` (generator.py:399-470 as called by E4EStyleGanDefenseModel.decode, src/defenses/ours/models.py:346).
+The mapping MLP (`style.*`) is not on that path: the latents come from the e4e encoder.
 
 State-dict keys follow the reference module (prefix = the layer's name inside Generator, e.g. 'conv1' / 'convs.1'):
   {p}.conv.weight [1,Cout,Cin,k,k]   {p}.conv.modulation.weight [Cin,D]   {p}.conv.modulation.bias [Cin]
@@ -27,6 +28,7 @@ class StyledConvSpec:
     res: int             # feature-map side
     demodulate: bool     # False for ToRGB
     activate: bool       # noise + FusedLeakyReLU (StyledConv) or plain bias (ToRGB)
+    upsample: bool = False   # StyledConv(upsample=True): stride-2 transposed conv + [1,3,3,1] blur; res = OUTPUT side
 
 
 def init_styled_conv_state_dict(spec: StyledConvSpec, seed: int = 0) -> dict:
@@ -42,4 +44,50 @@ def init_styled_conv_state_dict(spec: StyledConvSpec, seed: int = 0) -> dict:
         sd[f'{p}.activate.bias'] = 0.2 * torch.randn(spec.cout, generator=g)
     else:
         sd[f'{p}.bias'] = 0.2 * torch.randn(1, spec.cout, 1, 1, generator=g)
+    return sd
+
+
+@dataclass(frozen=True)
+class StyleGanSpec:
+    size: int                 # output side (power of two >= 8)
+    style_dim: int
+    n_latent: int             # log2(size) * 2 - 2 (generator.py:378)
+    const_channels: int
+    conv1: StyledConvSpec
+    to_rgb1: StyledConvSpec
+    convs: tuple              # (up, plain) per resolution, flattened: convs.0, convs.1, ...
+    to_rgbs: tuple
+
+
+def build_stylegan_spec(size: int, channel_multiplier: int = 2, width_div: int = 1, style_dim: int = 512) -> StyleGanSpec:
+    """channel table of Generator.__init__ (generator.py:322-332), optionally divided (tests); layer order of :334-376"""
+    import math
+    log_size = int(math.log2(size))
+    assert 2 ** log_size == size and size >= 8
+    table = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256 * channel_multiplier, 128: 128 * channel_multiplier,
+             256: 64 * channel_multiplier, 512: 32 * channel_multiplier, 1024: 16 * channel_multiplier}
+    ch = {k: max(4, v // width_div) for k, v in table.items()}
+    D = style_dim
+    conv1 = StyledConvSpec('conv1', ch[4], ch[4], 3, D, 4, True, True)
+    rgb1 = StyledConvSpec('to_rgb1', ch[4], 3, 1, D, 4, False, False)
+    convs, rgbs, cin = [], [], ch[4]
+    for i in range(3, log_size + 1):
+        r, co = 2 ** i, ch[2 ** i]
+        convs.append(StyledConvSpec(f'convs.{len(convs)}', cin, co, 3, D, r, True, True, True))
+        convs.append(StyledConvSpec(f'convs.{len(convs)}', co, co, 3, D, r, True, True))
+        rgbs.append(StyledConvSpec(f'to_rgbs.{len(rgbs)}', co, 3, 1, D, r, False, False))
+        cin = co
+    return StyleGanSpec(size, D, log_size * 2 - 2, ch[4], conv1, rgb1, tuple(convs), tuple(rgbs))
+
+
+def init_stylegan_state_dict(spec: StyleGanSpec, seed: int = 0) -> dict:
+    """the synthesis network's parameters and fixed noise buffers under the reference's key names (Generator.state_dict();
+    the constant blur kernels `*.blur.kernel` / `*.upsample.kernel` = [1,3,3,1] and the mapping MLP `style.*` are not read)"""
+    g = torch.Generator().manual_seed(seed)
+    sd = {'input.input': torch.randn(1, spec.const_channels, 4, 4, generator=g)}
+    for k, sp in enumerate((spec.conv1, spec.to_rgb1) + spec.convs + spec.to_rgbs):
+        sd.update(init_styled_conv_state_dict(sp, seed * 1000 + k + 1))
+    for i in range(1 + len(spec.convs)):                    # noise_0 at 4x4, then two per resolution (generator.py:349-352)
+        r = 2 ** ((i + 5) // 2)
+        sd[f'noises.noise_{i}'] = torch.randn(1, 1, r, r, generator=g)
     return sd

@@ -247,6 +247,13 @@ typedef struct ga_modout_desc {
 } ga_modout_desc;
 int ga_modout(const ga_modout_desc* d, void* stream);
 
+/* ToRGB's skip path (generator.py:29-46,286-288): Upsample = upfirdn2d(skip, outer(k,k)/16 * 4, up 2, pad (2, 1)), k = [1,3,3,1];
+ * per axis  out[2U] = 1/4 s[U-1] + 3/4 s[U],  out[2U+1] = 3/4 s[U] + 1/4 s[U+1]  (zero beyond the border).
+ *   forward : hi[n,2H,2W,C] += up(lo[n,H,W,C])          backward: lo[n,H,W,C] = up^T(hi)   (written, not accumulated)
+ * C % 4 == 0. */
+typedef struct ga_up2_blur_desc { const float* lo_in; float* hi; const float* hi_in; float* lo; int N, H, W, C; int backward; int _reserved; } ga_up2_blur_desc;
+int ga_up2_blur(const ga_up2_blur_desc* d, void* stream);
+
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
  * x: [rows][C], C % 4 == 0. */
@@ -335,7 +342,7 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
-                  GA_OP_MODOUT = 20 };
+                  GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -346,7 +353,7 @@ typedef struct ga_op {
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
-        ga_unary_desc un; ga_modout_desc mo;
+        ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

@@ -262,3 +262,26 @@ def test_styled_conv_plans_build_without_a_gpu():
     # backward: the latent gradient is written by the last layer's modulation^T and accumulated by the first one's
     mods = [d for d, n in zip(eng.bwd.descs, eng.bwd.names) if n.endswith('modulation^T')]
     assert len(mods) == 2 and not mods[0].addend and mods[1].addend
+
+
+def test_stylegan_generator_plans_build_without_a_gpu():
+    """Generator wiring (engine_stylegan.build_stylegan): layer count, latent slices shared between ToRGB and the next
+    up-sampling conv accumulate, the constant input gets no gradient op"""
+    from gen_adversarial_amd.engine_core import Act
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    spec = build_stylegan_spec(32, width_div=16, style_dim=64)
+    assert spec.n_latent == 8 and len(spec.convs) == 6 and len(spec.to_rgbs) == 3
+    sd = init_stylegan_state_dict(spec, 3)
+    eng = Engine.bare(2, device='cpu', dry_run=True)
+    lat = Act(eng, 2, 1, 1, spec.n_latent * spec.style_dim, 'latent')
+    img = eng.build_stylegan(sd, spec, lat)
+    eng.finish()
+    assert (img.h, img.w, img.c) == (32, 32, 4)
+    names = eng.bwd.names
+    assert 'conv1.dx' not in names and 'convs.0.dx' in names
+    mods = {n: d for d, n in zip(eng.bwd.descs, names) if n.endswith('modulation^T')}
+    assert len(mods) == 11
+    assert not mods['to_rgbs.2.modulation^T'].addend            # latent[:, 7]: one reader
+    # latent[:, 5] has two readers: the later layer's backward runs first and writes, the earlier one accumulates
+    assert not mods['convs.4.modulation^T'].addend and mods['to_rgbs.1.modulation^T'].addend
+    assert sum(n.endswith('skip_upsample') for n in eng.fwd.names) == 3
