@@ -22,7 +22,8 @@ GA_ACT_NONE, GA_ACT_SILU, GA_ACT_ELU, GA_ACT_RELU, GA_ACT_LRELU, GA_ACT_FLRELU =
 GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PRELU = 1, 2, 4, 8
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
  GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR, GA_OP_REP_SUM, GA_OP_INTERLEAVE2,
- GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR) = range(1, 22)
+ GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR, GA_OP_PIXELNORM,
+ GA_OP_LATENT_MIX, GA_OP_POOL_DENORM) = range(1, 25)
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -146,11 +147,26 @@ class Up2BlurDesc(C.Structure):
                 ('backward', i32), ('_reserved', i32)]
 
 
+class PixelnormDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('rows', C.c_long), ('C', i32)]
+
+
+class LatentMixDesc(C.Structure):
+    _fields_ = [('codes', fp), ('avg', fp), ('styles', fp), ('alpha', fp), ('out', fp), ('dout', fp), ('dcodes', fp),
+                ('R', i32), ('J', i32), ('D', i32), ('backward', i32)]
+
+
+class PoolDenormDesc(C.Structure):
+    _fields_ = [('x', fp), ('y', fp), ('dy', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('k', i32), ('ld', i32),
+                ('backward', i32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [('conv', ConvDesc), ('dw', DwDesc), ('red', ReduceDesc), ('se', SeExciteDesc), ('app', SeApplyDesc),
                 ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
                 ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc), ('rs', RepSumDesc), ('il', Interleave2Desc),
-                ('mp3', Maxpool3s2Desc), ('ap', AvgpoolActDesc), ('gc', GconvDesc), ('pr', PreluDesc), ('un', UnaryDesc), ('mo', ModoutDesc), ('ub', Up2BlurDesc)]
+                ('mp3', Maxpool3s2Desc), ('ap', AvgpoolActDesc), ('gc', GconvDesc), ('pr', PreluDesc), ('un', UnaryDesc), ('mo', ModoutDesc), ('ub', Up2BlurDesc), ('lm', LatentMixDesc),
+                ('pd', PoolDenormDesc), ('pn', PixelnormDesc)]
 
 
 class Op(C.Structure):
@@ -160,17 +176,19 @@ class Op(C.Structure):
 _KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_OP_SE_EXCITE: 'se',
                GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
                GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur', GA_OP_REP_SUM: 'rs',
-               GA_OP_INTERLEAVE2: 'il', GA_OP_MAXPOOL3S2: 'mp3', GA_OP_AVGPOOL_ACT: 'ap', GA_OP_GCONV: 'gc', GA_OP_PRELU: 'pr', GA_OP_UNARY: 'un', GA_OP_MODOUT: 'mo', GA_OP_UP2_BLUR: 'ub'}
+               GA_OP_INTERLEAVE2: 'il', GA_OP_MAXPOOL3S2: 'mp3', GA_OP_AVGPOOL_ACT: 'ap', GA_OP_GCONV: 'gc', GA_OP_PRELU: 'pr', GA_OP_UNARY: 'un', GA_OP_MODOUT: 'mo', GA_OP_UP2_BLUR: 'ub', GA_OP_PIXELNORM: 'pn',
+               GA_OP_LATENT_MIX: 'lm', GA_OP_POOL_DENORM: 'pd'}
 _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
               SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
               DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY,
               BlurDesc: GA_OP_BLUR, RepSumDesc: GA_OP_REP_SUM, Interleave2Desc: GA_OP_INTERLEAVE2,
               Maxpool3s2Desc: GA_OP_MAXPOOL3S2, AvgpoolActDesc: GA_OP_AVGPOOL_ACT, GconvDesc: GA_OP_GCONV,
-              PreluDesc: GA_OP_PRELU, UnaryDesc: GA_OP_UNARY, ModoutDesc: GA_OP_MODOUT, Up2BlurDesc: GA_OP_UP2_BLUR}
+              PreluDesc: GA_OP_PRELU, UnaryDesc: GA_OP_UNARY, ModoutDesc: GA_OP_MODOUT, Up2BlurDesc: GA_OP_UP2_BLUR,
+              PixelnormDesc: GA_OP_PIXELNORM, LatentMixDesc: GA_OP_LATENT_MIX, PoolDenormDesc: GA_OP_POOL_DENORM}
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
 
 
@@ -184,7 +202,8 @@ def _load():
                  ('ga_sampler_mix', SamplerDesc), ('ga_dml_mean', DmlDesc), ('ga_maxpool2', MaxpoolDesc),
                  ('ga_image_io', ImageIoDesc), ('ga_gauss_blur', BlurDesc), ('ga_interleave2', Interleave2Desc),
                  ('ga_maxpool3s2', Maxpool3s2Desc), ('ga_avgpool_act', AvgpoolActDesc), ('ga_gconv', GconvDesc), ('ga_prelu', PreluDesc),
-                 ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc), ('ga_up2_blur', Up2BlurDesc)):
+                 ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc), ('ga_up2_blur', Up2BlurDesc),
+                 ('ga_latent_mix', LatentMixDesc), ('ga_pool_denorm', PoolDenormDesc)):
         f = getattr(lib, n)
         f.argtypes = [C.POINTER(d), C.c_void_p]
         f.restype = C.c_int
@@ -199,6 +218,8 @@ def _load():
     lib.ga_plan_profile.restype = C.c_int
     lib.ga_rep_sum.argtypes = [fp, fp, C.c_long, C.c_long, C.c_int, C.c_int, C.c_void_p]
     lib.ga_rep_sum.restype = C.c_int
+    lib.ga_pixelnorm.argtypes = [fp, fp, C.c_long, C.c_int, C.c_void_p]
+    lib.ga_pixelnorm.restype = C.c_int
     lib.ga_graph_capture.argtypes = [C.POINTER(Op), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.ga_graph_capture.restype = C.c_int
     lib.ga_graph_launch.argtypes = [C.c_void_p, C.c_void_p]
@@ -239,13 +260,17 @@ _DIRECT = {ConvDesc: 'ga_conv2d', DwDesc: 'ga_dwconv5', ReduceDesc: 'ga_rowchan_
            SeApplyDesc: 'ga_se_apply', BilinearBwdDesc: 'ga_bilinear_up2_bwd', SamplerDesc: 'ga_sampler_mix',
            DmlDesc: 'ga_dml_mean', MaxpoolDesc: 'ga_maxpool2', ImageIoDesc: 'ga_image_io', BlurDesc: 'ga_gauss_blur',
            Interleave2Desc: 'ga_interleave2', Maxpool3s2Desc: 'ga_maxpool3s2', AvgpoolActDesc: 'ga_avgpool_act',
-           GconvDesc: 'ga_gconv', PreluDesc: 'ga_prelu', UnaryDesc: 'ga_unary', ModoutDesc: 'ga_modout', Up2BlurDesc: 'ga_up2_blur'}
+           GconvDesc: 'ga_gconv', PreluDesc: 'ga_prelu', UnaryDesc: 'ga_unary', ModoutDesc: 'ga_modout', Up2BlurDesc: 'ga_up2_blur',
+           LatentMixDesc: 'ga_latent_mix', PoolDenormDesc: 'ga_pool_denorm'}
 
 
 def run(desc, stream: int = 0):
     """Launch one op directly through its own C entry point."""
     if isinstance(desc, AxpbyDesc):
         check(lib.ga_axpby(desc.x, desc.y, desc.n, desc.alpha, desc.beta, stream), 'ga_axpby')
+        return
+    if isinstance(desc, PixelnormDesc):
+        check(lib.ga_pixelnorm(desc.x, desc.y, desc.rows, desc.C, stream), 'ga_pixelnorm')
         return
     if isinstance(desc, RepSumDesc):
         check(lib.ga_rep_sum(desc.x, desc.y, desc.rows, desc.inner, desc.rep, desc.accumulate, stream), 'ga_rep_sum')

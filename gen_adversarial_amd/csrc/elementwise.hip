@@ -549,6 +549,66 @@ __global__ void __launch_bounds__(256) up2_blur_kernel(const ga_up2_blur_desc d,
     }
 }
 
+// one wavefront per row
+__global__ void __launch_bounds__(256) pixelnorm_kernel(const float* __restrict__ x, float* __restrict__ y, const long rows, const int C) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const float* xr = x + r * C;
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += xr[c] * xr[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        const float inv = rsqrtf(acc / (float)C + 1e-8f);
+        for (int c = lane; c < C; c += 64) y[r * C + c] = xr[c] * inv;
+    }
+}
+
+__global__ void __launch_bounds__(256) latent_mix_kernel(const ga_latent_mix_desc d, const long total4) {
+    const int D4 = d.D / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i % D4); const int j = (int)((i / D4) % d.J);
+        const float a = d.alpha[j];
+        if (!d.backward) {
+            floatx4 c = ld4(d.codes + i * 4);
+            if (d.avg) c += ld4(d.avg + ((size_t)j * d.D + 4 * q));
+            *reinterpret_cast<floatx4*>(d.out + i * 4) = (1.0f - a) * c + a * ld4(d.styles + i * 4);
+        } else {
+            *reinterpret_cast<floatx4*>(d.dcodes + i * 4) = (1.0f - a) * ld4(d.dout + i * 4);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pool_denorm_kernel(const ga_pool_denorm_desc d, const long total) {
+    const int k = d.k, Wi = d.W * k;
+    if (!d.backward) {
+        const float inv = 0.5f / (float)(k * k);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {   // i = pooled pixel
+            const int w = (int)(i % d.W); long r = i / d.W;
+            const int h = (int)(r % d.H); const long n = r / d.H;
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int a = 0; a < k; ++a)
+                for (int b = 0; b < k; ++b)
+                    acc += ld4(d.x + (((size_t)n * d.H * k + (h * k + a)) * Wi + (w * k + b)) * 4);
+            float* o = d.y + ((((size_t)n * (d.H >> 1) + (h >> 1)) * (d.W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * d.ld;
+            floatx4 v = acc * inv + 0.5f;
+            v[3] = 0.f;
+            *reinterpret_cast<floatx4*>(o) = v;
+            for (int z = 4; z < d.ld; z += 4) *reinterpret_cast<floatx4*>(o + z) = floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        const float inv = 0.5f / (float)(k * k);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {   // i = generated pixel
+            const int X = (int)(i % Wi); long r = i / Wi;
+            const int Y = (int)(r % (d.H * k)); const long n = r / (d.H * k);
+            const int h = Y / k, w = X / k;
+            const float* g = d.dy + ((((size_t)n * (d.H >> 1) + (h >> 1)) * (d.W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * d.ld;
+            floatx4 v = ld4(g) * inv;
+            v[3] = 0.f;
+            *reinterpret_cast<floatx4*>(d.dx + i * 4) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // nn.PReLU as its own pass (forward / backward)
 // ---------------------------------------------------------------------------------------------------------------
@@ -992,6 +1052,36 @@ extern "C" int ga_up2_blur(const ga_up2_blur_desc* d, void* s) {
     if (d->backward && (!d->hi_in || !d->lo)) return GA_E_BADARG;
     const long total4 = (long)d->N * d->H * d->W * (d->C / 4) * (d->backward ? 1 : 4);
     hipLaunchKernelGGL(up2_blur_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_pixelnorm(const float* x, float* y, long rows, int C, void* s) {
+    ga::clear_stale_error();
+    if (!x || !y || rows <= 0 || C <= 0) return GA_E_BADARG;
+    const long blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(pixelnorm_kernel, dim3((unsigned)(blocks > 65535 ? 65535 : blocks)), dim3(256), 0, (hipStream_t)s, x, y, rows, C);
+    return check_launch();
+}
+
+extern "C" int ga_latent_mix(const ga_latent_mix_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || !d->alpha || d->R <= 0 || d->J <= 0 || d->D <= 0) return GA_E_BADARG;
+    if (d->D % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && (!d->codes || !d->styles || !d->out)) return GA_E_BADARG;
+    if (d->backward && (!d->dout || !d->dcodes)) return GA_E_BADARG;
+    const long total4 = (long)d->R * d->J * (d->D / 4);
+    hipLaunchKernelGGL(latent_mix_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
+    return check_launch();
+}
+
+extern "C" int ga_pool_denorm(const ga_pool_denorm_desc* d, void* s) {
+    ga::clear_stale_error();
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0 || d->ld < 4) return GA_E_BADARG;
+    if ((d->H | d->W) & 1 || d->ld % 4) return GA_E_UNSUPPORTED;
+    if (!d->backward && (!d->x || !d->y)) return GA_E_BADARG;
+    if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    const long total = (long)d->N * d->H * d->W * (d->backward ? d->k * d->k : 1);
+    hipLaunchKernelGGL(pool_denorm_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();
 }
 

@@ -80,7 +80,8 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
 
     @classmethod
     def bare(cls, rows: int, device='cuda:0', precision: str = 'bf16x3', store: Optional[WeightStore] = None,
-             dry_run: bool = False) -> "Engine":
+             dry_run: bool = False, rep: int = 1, resolution=None, alphas: Sequence[float] = (), noise_eps: float = 0.0,
+             need_backward: bool = True) -> "Engine":
         """An engine with empty plans: building blocks that are not yet part of a full defender (the StyleGAN2 layers of
         engine_stylegan.py) are emitted into it by their builders and closed with `finish()`; forward() / backward() then
         replay the plans as for a full engine."""
@@ -89,9 +90,12 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
         if self.device.type != 'cuda' and not dry_run:
             raise RuntimeError('the HIP engine needs a GPU device; there is no CPU fallback')
         self.store = store if store is not None else WeightStore(self.device)
-        self.has_nvae, self.spec, self.vspec, self.resolution = False, None, None, None
-        self.rows, self.rep, self.alphas, self.temperature, self.noise_eps, self.blur = rows, 1, [], 1.0, 0.0, False
-        self.share_encoder, self.enc_rows, self.need_backward = False, rows, True
+        if rows % rep:
+            raise ValueError('rows must be a multiple of the EoT repeat')
+        self.has_nvae, self.spec, self.vspec, self.resolution = False, None, None, (tuple(resolution) if resolution else None)
+        self.rows, self.rep, self.alphas, self.temperature = rows, rep, [float(a) for a in alphas], 1.0
+        self.noise_eps, self.blur = float(noise_eps), False
+        self.share_encoder, self.enc_rows, self.need_backward, self.image_s2d = False, rows, need_backward, False
         self.bytes, self.acts, self.version, self._sampler_descs, self._keep = 0, {}, 0, [], []
         self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
@@ -255,6 +259,20 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
     def _build(self, nvae_sd, vgg_sd):
         self.nvae_sd = nvae_sd
         self._scratch = {}
+        self.image_s2d = (not self.has_nvae) and isinstance(self.vspec, ResNetSpec)
+        x0 = self._build_input()
+        img = self._build_nvae(x0) if self.has_nvae else x0
+
+        # ---- classifier
+        n_nvae_steps = len(self._bwd_steps)
+        build = (self._build_resnet if isinstance(self.vspec, ResNetSpec) else
+                 self._build_e4e if isinstance(self.vspec, E4ESpec) else self._build_vgg)
+        self.logits = build(vgg_sd, img)
+
+        self._finish(n_nvae_steps)
+
+    def _build_input(self) -> Act:
+        """caller-visible boundary buffers + the image_io op (EoT repeat, input noise, clamp, NCHW -> NHWC); returns the image Act"""
         R = self.rows
         H = self.resolution[1]
 
@@ -291,7 +309,6 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
         # the NHWC image is kept at a pitch of IMG_LD = 8 channels (3 real + zero pad): the first convolutions then take
         # 16-B loads and the split-bf16 matrix path like every other layer instead of a scalar 3-channel gather
         # (a classifier-only ResNet engine takes the image in space-to-depth form: its 7x7/2 stem is then a 4x4/1 conv)
-        self.image_s2d = (not self.has_nvae) and isinstance(self.vspec, ResNetSpec)
         x0 = Act(self, R0, H // 2, H // 2, 4 * IMG_LD, 'x0') if self.image_s2d else Act(self, R0, H, H, IMG_LD, 'x0')
         io = L.ImageIoDesc()
         io.x_nchw, io.noise_nchw, io.noise_coef, io.y_nhwc = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef), _ptr(x0.t)
@@ -306,15 +323,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
-        img = self._build_nvae(x0) if self.has_nvae else x0
-
-        # ---- classifier
-        n_nvae_steps = len(self._bwd_steps)
-        build = (self._build_resnet if isinstance(self.vspec, ResNetSpec) else
-                 self._build_e4e if isinstance(self.vspec, E4ESpec) else self._build_vgg)
-        self.logits = build(vgg_sd, img)
-
-        self._finish(n_nvae_steps)
+        return x0
 
     def _finish(self, n_nvae_steps: int = 0):
         # ---- emit the backward plan: reverse registration order (classifier part first)
@@ -411,6 +420,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
         if alphas == self.alphas:
             return
         self.alphas = alphas
+        if getattr(self, 'alpha_dev', None) is not None:     # e4e defender: the alphas are device data, no descriptor changes
+            self.alpha_dev.copy_(torch.tensor(alphas, dtype=torch.float32))
+            return
         for d, idx in self._sampler_descs:
             d.alpha, d.one_minus_alpha = alphas[idx], 1.0 - alphas[idx]
         self.fwd.finalize()

@@ -12,16 +12,22 @@ from .engine_core import IMG_LD, RES_SCALE, Act, _ptr
 
 class E4EBuilder:
     # ------------------------------------------------------------------------------------------------ e4e encoder
-    def _build_e4e(self, esd, img: Act) -> torch.Tensor:
+    def _build_e4e(self, esd, img: Act, normalize: bool = False) -> torch.Tensor:
         """Encoder4Editing.forward (encoding/encoder.py:108-140; e4e_spec.py) on the NHWC image (taken as is: the caller's
-        normalisation, if any, is part of its input).  Returns the latents as [rows, style_count * 512]; `dlogits` is
+        normalisation, if any, is part of its input — or, with normalize, Normalize(0.5, 0.5) of an image in [0, 1] as the
+        input conv's prologue affine, abstract_models.py:177-178).  Returns the latents as [rows, style_count * 512]; `dlogits` is
         their cotangent."""
         es, R = self.vspec, self.rows
         if self.image_s2d:
             raise NotImplementedError
         inp = self.devd('e4e.input', lambda: F.fold_e4e_input(esd, IMG_LD))
         t0 = Act(self, R, img.h, img.w, es.base, 'e4e.input.conv')
-        self.conv(self.fwd, 'e4e.input.conv', img.t, inp['w'], t0.t, bias=inp['b'], K=3, pad=1)
+        nrm, nrm_b = {}, {}
+        if normalize:
+            c = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
+            nrm = dict(pro_scale=c['two'], pro_shift=c['mone'])
+            nrm_b = dict(dact_x=img.t, dact_scale=c['two'], dact_shift=c['mone'], dact_act=L.GA_ACT_NONE)
+        self.conv(self.fwd, 'e4e.input.conv', img.t, inp['w'], t0.t, bias=inp['b'], K=3, pad=1, **nrm)
         x = Act(self, R, img.h, img.w, es.base, 'e4e.input')
         pr = L.PreluDesc()
         pr.x, pr.slope, pr.y, pr.rows, pr.C, pr.backward = _ptr(t0.t), _ptr(inp['slope']), _ptr(x.t), R * img.h * img.w, es.base, 0
@@ -34,7 +40,7 @@ class E4EBuilder:
                                                                  R * img.h * img.w, es.base, 1)
             self.bwd.add(b, 'e4e.input.prelu^T')
             t0.g_written = True
-            self.grad_conv('e4e.input.conv^T', t0.g, inp['w_bwd'], img, K=3, pad=1)
+            self.grad_conv('e4e.input.conv^T', t0.g, inp['w_bwd'], img, K=3, pad=1, **nrm_b)
         self._bwd_steps.append(bwd_input)
 
         feats = {}

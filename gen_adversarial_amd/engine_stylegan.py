@@ -25,8 +25,8 @@ import torch
 
 from . import _lib as L
 from . import folding as F
-from .engine_core import Act, _ptr
-from .stylegan_spec import StyledConvSpec
+from .engine_core import IMG_LD, Act, _ptr
+from .stylegan_spec import LR_MLP, N_MLP, StyledConvSpec
 
 
 class LatentSlice:
@@ -159,6 +159,82 @@ class StyleGanBuilder:
             i += 2
         latent.g_written = True
         return img
+
+    def build_mapping(self, gsd, z: torch.Tensor) -> torch.Tensor:
+        """Generator.style (generator.py:306-317) on z [rows, D]: PixelNorm + 8 x (EqualLinear, fused leaky ReLU).  Forward only:
+        on the defender's path z is fresh noise (src/defenses/ours/models.py:118-120)."""
+        rows, D = z.shape
+        wts = self.devd('sg.mapping', lambda: F.fold_mapping(gsd, N_MLP, LR_MLP))
+        h = self.alloc((rows, 1, 1, D))
+        pn = L.PixelnormDesc()
+        pn.x, pn.y, pn.rows, pn.C = _ptr(z), _ptr(h), rows, D
+        self.fwd.add(pn, 'sg.mapping.pixelnorm')
+        for k in range(1, N_MLP + 1):
+            nxt = self.alloc((rows, 1, 1, D))
+            self.conv(self.fwd, f'sg.mapping.fc{k}', h, wts[f'w{k}'], nxt, bias=wts[f'b{k}'], K=1)
+            m = L.ModoutDesc()
+            m.t, m.out, m.N, m.P, m.C, m.act, m.backward = _ptr(nxt), _ptr(nxt), 1, rows, D, L.GA_ACT_FLRELU, 0
+            self.fwd.add(m, f'sg.mapping.act{k}')
+            h = nxt
+        return h
+
+    def build_e4e_defense(self, esd, espec, gsd, gspec, latent_avg, csd, cspec, pool_to: int):
+        """E4EStyleGanDefenseModel.purify + classifier (src/defenses/ours/models.py:80-132; abstract_models.py:161-193) as one
+        forward / backward plan pair:  image_io -> Normalize -> e4e encoder (+ latent_avg) -> mix with mapping(noise) ->
+        StyleGAN2 synthesis -> face_pool + de-normalise -> ResNet classifier.  Caller-visible: x_in, eps[0] (the N(0,1) noise
+        [rows, n_latent, D]), logits / dlogits, dx, purified_s2d; the mixing alphas live in a device buffer (set_alphas)."""
+        R, J, D = self.rows, espec.style_count, espec.style_dim
+        assert (gspec.n_latent, gspec.style_dim) == (J, D), 'encoder and generator disagree on the latent layout'
+        assert gspec.size % pool_to == 0 and pool_to % 2 == 0, 'face_pool is built as a k x k mean'
+        self.image_s2d = False
+        x0 = self._build_input()
+        self.vspec = espec
+        codes = self._build_e4e(esd, x0, normalize=True)                       # [R, J*D]; cotangent buffer = self.dlogits
+        dcodes = self.dlogits
+        self.eps = [self.alloc((R, J, D))]
+        styles = self.build_mapping(gsd, self.eps[0].view(R * J, D))
+        avg = self.devd('sg.latent_avg', lambda: {'a': latent_avg.reshape(J, D)})['a'] if latent_avg is not None else None
+        self.alpha_dev = self.alloc((J,))
+        self.alpha_dev.copy_(torch.tensor(self.alphas, dtype=torch.float32))
+        latent = Act(self, R, 1, 1, J * D, 'sg.latent')
+        mx = L.LatentMixDesc()
+        mx.codes, mx.avg, mx.styles, mx.alpha, mx.out = _ptr(codes), _ptr(avg), _ptr(styles), _ptr(self.alpha_dev), _ptr(latent.t)
+        mx.R, mx.J, mx.D, mx.backward = R, J, D, 0
+        self.fwd.add(mx, 'latent_mix')
+
+        def bwd_mix():
+            b = L.LatentMixDesc()
+            b.alpha, b.dout, b.dcodes, b.R, b.J, b.D, b.backward = _ptr(self.alpha_dev), _ptr(latent.g), _ptr(dcodes), R, J, D, 1
+            self.bwd.add(b, 'latent_mix^T')
+        self._bwd_steps.append(bwd_mix)
+
+        img = self.build_stylegan(gsd, gspec, latent)
+        k = gspec.size // pool_to
+        pooled = Act(self, R, pool_to // 2, pool_to // 2, 4 * IMG_LD, 'purified_s2d')
+        pd = L.PoolDenormDesc()
+        pd.x, pd.y, pd.N, pd.H, pd.W, pd.k, pd.ld, pd.backward = _ptr(img.t), _ptr(pooled.t), R, pool_to, pool_to, k, IMG_LD, 0
+        self.fwd.add(pd, 'face_pool_denorm')
+
+        def bwd_pool():
+            b = L.PoolDenormDesc()
+            b.dy, b.dx, b.N, b.H, b.W, b.k, b.ld, b.backward = _ptr(pooled.g), _ptr(img.g), R, pool_to, pool_to, k, IMG_LD, 1
+            self.bwd.add(b, 'face_pool_denorm^T')
+            img.g_written = True
+        self._bwd_steps.append(bwd_pool)
+
+        self.vspec, self.image_s2d = cspec, True
+        self.logits = self._build_resnet(csd, pooled)
+        self.image_s2d = False                                   # x0 (the defender's input) is a plain NHWC image
+        self.purified_s2d = pooled
+        self._finish(0)
+        return self
+
+    def purified_nchw(self) -> torch.Tensor:
+        """the purified image of the last forward, [rows, 3, H, W] in [0, 1] (classifier input before its normalisation)"""
+        t = self.purified_s2d.t
+        n, h2, w2, _ = t.shape
+        v = t.view(n, h2, w2, 2, 2, IMG_LD)[..., :3]
+        return v.permute(0, 5, 1, 3, 2, 4).reshape(n, 3, 2 * h2, 2 * w2).contiguous()
 
     def _unary(self, plan, name, mode, x, g, y, eps=0.0):
         u = L.UnaryDesc()

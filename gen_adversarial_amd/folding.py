@@ -426,3 +426,13 @@ def upsample_conv_weights(w: torch.Tensor) -> dict:
             out[f'up{a}{b}'] = f32(conv_fwd_layout(wp))
     out['up_bwd'] = f32(conv_fwd_layout(G.permute(1, 0, 2, 3)))
     return out
+
+
+def fold_mapping(sd: SD, n_mlp: int, lr_mul: float) -> dict:
+    """Generator.style's EqualLinear stack (generator.py:85-92,306-317): weight * (lr_mul / sqrt(in)), bias * lr_mul"""
+    out = {}
+    for k in range(1, n_mlp + 1):
+        w = sd[f'style.{k}.weight'].double()
+        out[f'w{k}'] = f32(w * (lr_mul / w.shape[1] ** 0.5))
+        out[f'b{k}'] = f32(sd[f'style.{k}.bias'].double() * lr_mul)
+    return out

@@ -4,7 +4,8 @@ Parameter layout of the StyleGAN2 synthesis layers the e4e defender decodes with
 (generator.py:229-265: ModulatedConv2d, NoiseInjection, FusedLeakyReLU), `ToRGB` (generator.py:268-290: 1x1 modulated conv
 without demodulation, bias, up-sampled skip) and the synthesis network's wiring for `input_is_latent=True,
 randomize_noise=False` (generator.py:399-470 as called by E4EStyleGanDefenseModel.decode, src/defenses/ours/models.py:346).
-The mapping MLP (`style.*`) is not on that path: the latents come from the e4e encoder.
+The mapping MLP (`style.*`, generator.py:306-317) turns the defender's Gaussian noise into the styles it mixes with the
+encoder's codes (src/defenses/ours/models.py:118-124): forward only.
 
 State-dict keys follow the reference module (prefix = the layer's name inside Generator, e.g. 'conv1' / 'convs.1'):
   {p}.conv.weight [1,Cout,Cin,k,k]   {p}.conv.modulation.weight [Cin,D]   {p}.conv.modulation.bias [Cin]
@@ -47,6 +48,9 @@ def init_styled_conv_state_dict(spec: StyledConvSpec, seed: int = 0) -> dict:
     return sd
 
 
+N_MLP, LR_MLP = 8, 0.01          # pSp builds Generator(size, 512, 8, channel_multiplier=2) (psp.py:25); lr_mlp default 0.01
+
+
 @dataclass(frozen=True)
 class StyleGanSpec:
     size: int                 # output side (power of two >= 8)
@@ -82,11 +86,15 @@ def build_stylegan_spec(size: int, channel_multiplier: int = 2, width_div: int =
 
 def init_stylegan_state_dict(spec: StyleGanSpec, seed: int = 0) -> dict:
     """the synthesis network's parameters and fixed noise buffers under the reference's key names (Generator.state_dict();
-    the constant blur kernels `*.blur.kernel` / `*.upsample.kernel` = [1,3,3,1] and the mapping MLP `style.*` are not read)"""
+    the constant blur kernels `*.blur.kernel` / `*.upsample.kernel` = [1,3,3,1] are not read)"""
     g = torch.Generator().manual_seed(seed)
     sd = {'input.input': torch.randn(1, spec.const_channels, 4, 4, generator=g)}
     for k, sp in enumerate((spec.conv1, spec.to_rgb1) + spec.convs + spec.to_rgbs):
         sd.update(init_styled_conv_state_dict(sp, seed * 1000 + k + 1))
+    D = spec.style_dim
+    for k in range(1, N_MLP + 1):                           # mapping network: PixelNorm + 8 EqualLinear(lr_mul=0.01, fused_lrelu)
+        sd[f'style.{k}.weight'] = torch.randn(D, D, generator=g) / LR_MLP        # generator.py:74 (randn / lr_mul)
+        sd[f'style.{k}.bias'] = 10.0 * torch.randn(D, generator=g)               # used as bias * lr_mul
     for i in range(1 + len(spec.convs)):                    # noise_0 at 4x4, then two per resolution (generator.py:349-352)
         r = 2 ** ((i + 5) // 2)
         sd[f'noises.noise_{i}'] = torch.randn(1, 1, r, r, generator=g)

@@ -254,6 +254,29 @@ int ga_modout(const ga_modout_desc* d, void* stream);
 typedef struct ga_up2_blur_desc { const float* lo_in; float* hi; const float* hi_in; float* lo; int N, H, W, C; int backward; int _reserved; } ga_up2_blur_desc;
 int ga_up2_blur(const ga_up2_blur_desc* d, void* stream);
 
+/* PixelNorm on [rows, C] vectors (generator.py:10-15): y = x * rsqrt(mean_c(x^2) + 1e-8); the mapping network's first step.
+ * Forward only: on this path its input is fresh Gaussian noise (E4EStyleGanDefenseModel.purify, src/defenses/ours/models.py:118-120). */
+int ga_pixelnorm(const float* x, float* y, long rows, int C, void* stream);
+
+/* Latent mixing of the e4e defender (src/defenses/ours/models.py:116-127 + pSp.encode's latent_avg, psp.py:93-103):
+ *   forward : out[r, j, :] = (1 - alpha[j]) * (codes[r, j, :] + avg[j, :]) + alpha[j] * styles[r, j, :]
+ *   backward: dcodes[r, j, :] = (1 - alpha[j]) * dout[r, j, :]
+ * codes / styles / out / dout / dcodes: [R, J, D]; avg: [J, D] or NULL; alpha: [J] (device).  D % 4 == 0. */
+typedef struct ga_latent_mix_desc {
+    const float* codes; const float* avg; const float* styles; const float* alpha; float* out;
+    const float* dout; float* dcodes; int R, J, D; int backward;
+} ga_latent_mix_desc;
+int ga_latent_mix(const ga_latent_mix_desc* d, void* stream);
+
+/* pSp.face_pool + de-normalisation + hand-over to the classifier (psp.py:26,117; abstract_models.py:184-185): k x k average
+ * pooling of the generated image [N, k*H, k*W, 4] (lanes 0..2 = RGB in [-1, 1]) and y = 0.5 * mean + 0.5, written as the
+ * space-to-depth image [N, H/2, W/2, 4, ld] the ResNet stem reads (pixel (h, w) -> phase (h&1)*2 + (w&1); lanes >= 3 zero).
+ *   backward: dx[n, k*h + a, k*w + b, c] = 0.5 / k^2 * dy[n, h, w, c]  (c < 3; lane 3 zero).   H, W even; ld % 4 == 0. */
+typedef struct ga_pool_denorm_desc {
+    const float* x; float* y; const float* dy; float* dx; int N, H, W, k, ld; int backward;
+} ga_pool_denorm_desc;
+int ga_pool_denorm(const ga_pool_denorm_desc* d, void* stream);
+
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
  * x: [rows][C], C % 4 == 0. */
@@ -342,7 +365,8 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_BILINEAR_BWD = 6, GA_OP_SAMPLER = 7, GA_OP_DML = 8, GA_OP_MAXPOOL = 9, GA_OP_IMAGE_IO = 10,
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
-                  GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21 };
+                  GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21, GA_OP_PIXELNORM = 22, GA_OP_LATENT_MIX = 23,
+                  GA_OP_POOL_DENORM = 24 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -353,7 +377,8 @@ typedef struct ga_op {
         ga_bilinear_up2_bwd_desc bil; ga_sampler_desc smp; ga_dml_desc dml; ga_maxpool2_desc mp; ga_image_io_desc io;
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
-        ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub;
+        ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub; ga_latent_mix_desc lm; ga_pool_denorm_desc pd;
+        struct { const float* x; float* y; long rows; int C; } pn;
     } u;
 } ga_op;
 /* runs ops[0..n); returns 0 or the first failing op's error; *failed_index set when non-NULL */

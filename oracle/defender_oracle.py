@@ -138,3 +138,24 @@ def eot_defender(nvae_sd, nvae_spec, vgg_sd, vgg_spec, image: torch.Tensor, eot_
     logits, purified = nvae_defender(nvae_sd, nvae_spec, vgg_sd, vgg_spec, x, alphas, eps, input_noise,
                                      noise_eps, blur, temperature)
     return torch.mean(logits, dim=0, keepdim=True), purified
+
+
+def e4e_defender_call(esd, espec, gsd, gspec, latent_avg, csd, cspec, x01, alphas, z, pool_to: int):
+    """E4EStyleGanDefenseModel (src/defenses/ours/models.py:80-132) behind MLVGMDefenseModel.__call__ (abstract_models.py:161-193)
+    for a batch already repeated / noised / clamped to [0, 1]:
+      normalize(0.5, 0.5) -> pSp.encode (encoder + latent_avg, psp.py:89-103) -> codes mixed with mapping(z) per latent index
+      (models.py:116-127; z [B, n_latent, D] ~ N(0, 1) supplied by the caller) -> pSp.decode (generator, fixed noise buffers,
+      face_pool; psp.py:112-118) -> denormalize -> classifier.  face_pool = AdaptiveAvgPool2d to pool_to (256 in the reference;
+      a k x k mean when the generator size is a multiple of it).  Returns (logits, purified image in [~0, ~1])."""
+    from oracle.e4e_oracle import e4e_encode
+    from oracle import stylegan_oracle as S
+    codes = e4e_encode(esd, espec, (x01 - 0.5) / 0.5)
+    if latent_avg is not None:
+        codes = codes + latent_avg.unsqueeze(0)
+    styles = S.mapping_network(gsd, z)
+    a = torch.tensor(list(alphas), dtype=codes.dtype).view(1, -1, 1)
+    codes = (1 - a) * codes + a * styles
+    img = S.generator_forward(gsd, gspec, codes)
+    img = F.adaptive_avg_pool2d(img, (pool_to, pool_to))
+    purified = img * 0.5 + 0.5
+    return resnet_classifier_call(csd, cspec, purified), purified

@@ -114,3 +114,14 @@ def generator_forward(sd, spec, latent):
         skip = to_rgb(sd, f'to_rgbs.{k}', out, latent[:, i + 2], skip)
         i += 2
     return skip
+
+
+def mapping_network(sd, z, n_mlp: int = 8, lr_mul: float = 0.01):
+    """Generator.style (generator.py:306-317): PixelNorm (generator.py:10-15) + n_mlp EqualLinear(lr_mul, 'fused_lrelu')
+    (generator.py:85-92: linear with weight * (lr_mul / sqrt(in)), then fused_leaky_relu with bias * lr_mul); z [..., D]"""
+    h = z * torch.rsqrt(torch.mean(z ** 2, dim=-1, keepdim=True) + 1e-8)
+    for k in range(1, n_mlp + 1):
+        w = sd[f'style.{k}.weight']
+        h = F.linear(h, w * ((1.0 / math.sqrt(w.shape[1])) * lr_mul))
+        h = F.leaky_relu(h + sd[f'style.{k}.bias'] * lr_mul, 0.2) * 2 ** 0.5
+    return h

@@ -1,0 +1,75 @@
+"""
+GPU parity of the composed e4e + StyleGAN2 defender (E4EStyleGanDefenseModel, src/defenses/ours/
+models.py:80-132, behind MLVGMDefenseModel.__call__, abstract_models.py:161-193) against the CPU oracle
+(oracle/defender_oracle.e4e_defender_call) on a reduced configuration: quarter-width IR-SE encoder, 1/8-width 64-px generator,
+face_pool to 32 px, 1/8-width ResNet.  Also the small ops of the path (PixelNorm + mapping MLP, latent mixing, face_pool +
+de-normalisation into the classifier's space-to-depth layout).
+Tolerance 1e-3 absolute on logits and purified image (BASELINE.json north_star); input gradients in relative L2 (PReLU /
+leaky-ReLU / ReLU / max-pool kinks along ~150 layers: see test_e4e_gpu.py and test_stylegan_gpu.py).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from test_host_cpu import _small_e4e_defense   # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def test_mapping_network_matches_oracle():
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    from oracle import stylegan_oracle as S
+    spec = build_stylegan_spec(16, width_div=8, style_dim=512)
+    sd = init_stylegan_state_dict(spec, 2)
+    z = torch.randn(36, 512, generator=torch.Generator().manual_seed(1))
+    ref = S.mapping_network(sd, z)
+    for precision, tol in (('fp32', 2e-5), ('bf16x3', 1e-3)):
+        eng = Engine.bare(36, device=DEV, precision=precision)
+        zb = eng.alloc((36, 512))
+        out = eng.build_mapping(sd, zb)
+        eng.finish()
+        zb.copy_(z.to(DEV))
+        eng.forward()
+        e = (out.view(36, 512).cpu() - ref).abs().max().item()
+        print(f'mapping network [{precision}]: err {e:.2e} of {ref.abs().max().item():.2e}')
+        assert e < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])
+def test_e4e_defender_matches_oracle(precision, tol):
+    from oracle import defender_oracle as D
+    rows, rep = 4, 2
+    eng, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(rows, rep, DEV, False, precision)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    z = torch.randn(rows, gspec.n_latent, gspec.style_dim, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    logits, purified = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, xr.repeat_interleave(rep, dim=0), alphas, z, 32)
+    cot = torch.randn(logits.shape, generator=gen)
+    (gx,) = torch.autograd.grad((logits * cot).sum(), [xr])
+
+    eng.x_in.copy_(x.to(DEV))
+    eng.eps[0].copy_(z.to(DEV))
+    eng.forward()
+    e_p = (eng.purified_nchw().cpu() - purified.detach()).abs().max().item()
+    e_l = (eng.logits.view(rows, -1).cpu() - logits.detach()).abs().max().item()
+    eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
+    eng.backward()
+    rel = ((eng.dx.cpu() - gx).double().norm() / gx.double().norm()).item()
+    print(f'e4e defender [{precision}]: {len(eng.fwd)} + {len(eng.bwd)} ops; purified err {e_p:.2e} logits err {e_l:.2e} '
+          f'(|logits| {logits.abs().max().item():.2f}); input-grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
+    assert e_p < tol and e_l < tol * max(1.0, logits.abs().max().item())
+    assert rel < 3e-2
+
+    # the mixing alphas are device data: changing them needs no re-build, and alpha = 1 everywhere cuts the encoder off
+    eng.set_alphas([1.0] * gspec.n_latent)
+    eng.forward()
+    eng.backward()
+    assert eng.dx.abs().max().item() == 0.0
+    l1, _ = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, x.repeat_interleave(rep, dim=0), [1.0] * gspec.n_latent, z, 32)
+    assert (eng.logits.view(rows, -1).cpu() - l1).abs().max().item() < tol * max(1.0, l1.abs().max().item())

@@ -285,3 +285,35 @@ def test_stylegan_generator_plans_build_without_a_gpu():
     # latent[:, 5] has two readers: the later layer's backward runs first and writes, the earlier one accumulates
     assert not mods['convs.4.modulation^T'].addend and mods['to_rgbs.1.modulation^T'].addend
     assert sum(n.endswith('skip_upsample') for n in eng.fwd.names) == 3
+
+
+def _small_e4e_defense(rows=2, rep=1, device='cpu', dry_run=True, precision='bf16x3'):
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    size, res = 64, 64
+    espec = build_e4e_spec(size, 4, (1, 1, 1, 1))
+    esd = init_e4e_state_dict(size, 4, 3, (1, 1, 1, 1))
+    gspec = build_stylegan_spec(size, width_div=8, style_dim=espec.style_dim)
+    gsd = init_stylegan_state_dict(gspec, 4)
+    cspec = build_resnet_spec(2, 8, (1, 1, 1, 1))
+    csd = init_resnet_state_dict(2, 8, 5, (1, 1, 1, 1))
+    g = torch.Generator().manual_seed(6)
+    avg = 0.5 * torch.randn(gspec.n_latent, gspec.style_dim, generator=g)
+    alphas = [0.1 * (j % 4) for j in range(gspec.n_latent)]
+    eng = Engine.bare(rows, device=device, dry_run=dry_run, precision=precision, rep=rep, resolution=(3, res, res), alphas=alphas)
+    eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=32)
+    return eng, (esd, espec, gsd, gspec, avg, csd, cspec, alphas)
+
+
+def test_e4e_defense_plans_build_without_a_gpu():
+    """encoder -> latent mixing -> synthesis -> face_pool -> classifier as one plan pair (engine_stylegan.build_e4e_defense)"""
+    eng, _ = _small_e4e_defense()
+    f, b = eng.fwd.names, eng.bwd.names
+    assert f[0] == 'image_in' and b[-1] == 'image_in^T'
+    order = [f.index(n) for n in ('e4e.input.conv', 'sg.mapping.pixelnorm', 'latent_mix', 'conv1.modulation', 'face_pool_denorm', 'resnet.conv1')]
+    assert order == sorted(order)
+    rorder = [b.index(n) for n in ('resnet.conv1^T', 'face_pool_denorm^T', 'conv1.modulation^T', 'latent_mix^T', 'e4e.w0.grad', 'e4e.input.conv^T')]
+    assert rorder == sorted(rorder)
+    assert not any(n.startswith('sg.mapping') for n in b)          # the mapping network sees noise only: no backward
+    assert eng.logits.shape[0] == 2 and eng.eps[0].shape == (2, 10, 128)
