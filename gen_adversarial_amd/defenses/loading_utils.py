@@ -12,7 +12,7 @@ E4E / Style-Transformer loaders are the "next" rows of SURVEY.md §8 and raise N
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -121,5 +121,63 @@ def load_ResNext50(path: str, device: str, n_classes: int = 4) -> ResNetWeights:
                          width_per_group=w2.shape[1] * width_div)
 
 
-load_E4EStyleGan = _next('load_E4EStyleGan')
+@dataclass
+class E4EWeights:
+    """what pSp holds for the defender (StyleGan_E4E/psp.py:15-125): encoder / decoder state dicts (prefixes stripped),
+    latent_avg, the training options; specs are derived from the tensor shapes"""
+    encoder_sd: Dict[str, torch.Tensor]
+    encoder_spec: object
+    decoder_sd: Dict[str, torch.Tensor]
+    decoder_spec: object
+    latent_avg: Optional[torch.Tensor]
+    opts: dict
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+
+def load_E4EStyleGan(checkpoint_path: str, device: str) -> E4EWeights:
+    """src/defenses/loading_utils.py:37-48 + pSp.load_weights (psp.py:39-46,119-125): checkpoint keys 'state_dict' (with
+    'encoder.' / 'decoder.' prefixes), 'latent_avg', 'opts'.  Widths and depths are read off the tensors, so reduced test
+    checkpoints load too."""
+    from ..e4e_spec import build_e4e_spec
+    from ..stylegan_spec import build_stylegan_spec
+    ckpt = _torch_load(checkpoint_path)
+    opts = dict(ckpt['opts'])
+    sd = ckpt['state_dict']
+    enc = {k[len('encoder.'):]: v for k, v in sd.items() if k.startswith('encoder.')}
+    dec = {k[len('decoder.'):]: v for k, v in sd.items() if k.startswith('decoder.')}
+    if opts.get('encoder_type', 'Encoder4Editing') != 'Encoder4Editing':
+        raise NotImplementedError(f"encoder_type {opts.get('encoder_type')!r}: pSp only builds Encoder4Editing (psp.py:32-38)")
+    size = int(opts['stylegan_size'])
+    depths = []
+    i = 0
+    while f'body.{i}.res_layer.1.weight' in enc:
+        depths.append(enc[f'body.{i}.res_layer.1.weight'].shape[0])
+        i += 1
+    units = tuple(depths.count(d) for d in sorted(set(depths)))
+    espec = build_e4e_spec(size, 64 // enc['input_layer.0.weight'].shape[0], units)
+    c4 = dec['conv1.conv.weight'].shape[1]
+    gspec = build_stylegan_spec(size, 2, 512 // c4, dec['conv1.conv.modulation.weight'].shape[1])
+    for sp in (gspec.conv1, gspec.to_rgb1) + gspec.convs + gspec.to_rgbs:
+        got = tuple(dec[f'{sp.prefix}.conv.weight'].shape)
+        if got != (1, sp.cout, sp.cin, sp.kernel, sp.kernel):
+            raise ValueError(f'decoder.{sp.prefix}.conv.weight has shape {got}, expected {(1, sp.cout, sp.cin, sp.kernel, sp.kernel)}')
+    if 'latent_avg' in ckpt:
+        avg = ckpt['latent_avg'].float()
+        if avg.dim() == 1:
+            avg = avg.view(1, -1).expand(gspec.n_latent, -1)
+        avg = avg.reshape(gspec.n_latent, gspec.style_dim).contiguous()
+    elif opts.get('start_from_latent_avg', False):
+        raise NotImplementedError("checkpoint without 'latent_avg': the reference estimates it from 10000 random latents (psp.py:122-125)")
+    else:
+        avg = None
+    if not opts.get('start_from_latent_avg', False):
+        avg = None
+    return E4EWeights(enc, espec, dec, gspec, avg, opts)
+
+
 load_TranStyleGan = _next('load_TranStyleGan')

@@ -1,14 +1,15 @@
 """
 Concrete classifier / defender classes with the reference's names and constructor signatures
 (src/defenses/ours/models.py:17-353).  The CelebA-identities pair (VGG-11 classifier + NVAE defender) and the gender
-ResNet-50 classifier are built; the e4e/StyleGAN2 purifier and the cars pair (ResNeXt-50 + Style-Transformer) are "next" rows.
+ResNet-50 classifier with the e4e + StyleGAN2 purifier are built; the Style-Transformer purifier of the cars pair is a "next" row.
 """
 from __future__ import annotations
 
 import torch
 
 from ...engine import Engine
-from ..loading_utils import load_NVAE, load_ResNet50, load_ResNext50, load_Vgg11, NVAEWeights
+from ..loading_utils import (E4EWeights, NVAEWeights, load_E4EStyleGan, load_NVAE, load_ResNet50, load_ResNext50,
+                             load_Vgg11)
 from .abstract_models import BaseClassificationModel, MLVGMDefenseModel
 
 
@@ -78,5 +79,46 @@ def _next(name, what):
     return _NotBuilt
 
 
-E4EStyleGanDefenseModel = _next('E4EStyleGanDefenseModel', 'e4e + StyleGAN2 purifier (models.py:80-132)')
+class E4EStyleGanDefenseModel(MLVGMDefenseModel, torch.nn.Module):
+    """e4e encoder + StyleGAN2 purifier (models.py:80-132): encode, mix every latent index with a freshly mapped style
+    (alpha per index), decode with the fixed noise buffers, face_pool; (0.5, 0.5) normalisation around the autoencoder.
+    One HIP plan pair per (rows, EoT) including the ResNet classifier (engine_stylegan.build_e4e_defense).
+    Deliberate differences: generator sizes below 256 px (reduced test checkpoints) skip face_pool instead of being enlarged
+    to 256; the Gaussian-blur pre-processing is not wired for this defender yet."""
+
+    def __init__(self, classifier: BaseClassificationModel, autoencoder_path: str,
+                 interpolation_alphas: tuple, alpha_attenuation: float = 1.0, initial_noise_eps: float = 0.0,
+                 apply_gaussian_blur: bool = False, device: str = 'cpu'):
+        torch.nn.Module.__init__(self)
+        MLVGMDefenseModel.__init__(self, classifier, autoencoder_path, interpolation_alphas, alpha_attenuation,
+                                   initial_noise_eps, apply_gaussian_blur, device, (0.5, 0.5, 0.5), (0.5, 0.5, 0.5))
+        n = self.autoencoder.decoder_spec.n_latent
+        if len(self.interpolation_alphas) != n:
+            raise ValueError(f'{n} interpolation alphas expected (one per latent index), got {len(self.interpolation_alphas)}')
+
+    def load_autoencoder(self, model_path: str, device: str) -> E4EWeights:
+        return load_E4EStyleGan(model_path, device)
+
+    def _make_engine(self, rows: int, rep: int, with_noise: bool = True) -> Engine:
+        ae, clf = self.autoencoder, self.classifier.classifier
+        if self.blur_input and with_noise:
+            raise NotImplementedError('apply_gaussian_blur is not wired for the e4e defender yet')
+        res = getattr(self, 'image_size', 256)
+        eng = Engine.bare(rows, device=self.device, store=self._store, rep=rep, resolution=(3, res, res),
+                          alphas=self.interpolation_alphas, noise_eps=self.eps if with_noise else 0.0)
+        size = ae.decoder_spec.size
+        return eng.build_e4e_defense(ae.encoder_sd, ae.encoder_spec, ae.decoder_sd, ae.decoder_spec, ae.latent_avg,
+                                     clf.state_dict, clf.spec, pool_to=min(256, size))
+
+    def forward_rows(self, batch: torch.Tensor, rep: int = 1, preds_only: bool = True):
+        self.image_size = batch.shape[-1]
+        return super().forward_rows(batch, rep, preds_only)
+
+    def purify(self, batch: torch.Tensor) -> torch.Tensor:
+        """normalised images (B,3,H,W) in [-1, 1] -> normalised reconstructions, as the reference's purify (models.py:105-132);
+        values outside [-1, 1] are clamped at the engine's image boundary"""
+        self.image_size = batch.shape[-1]
+        return self._run(batch * 0.5 + 0.5, 1, True, with_noise=False)[1] * 2.0 - 1.0
+
+
 TransStyleGanDefenseModel = _next('TransStyleGanDefenseModel', 'Style-Transformer purifier (models.py:277-353)')

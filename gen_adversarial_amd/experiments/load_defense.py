@@ -5,8 +5,8 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `args.attacks` and attaches `defense_model.get_purified`.
 
 Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only), 'ablation' (noise / blur) and 'ours'
-(NVAE purifier); experiments 'gender' (ResNet-50, 256x256) and 'cars' (ResNeXt-50, 128x128) with 'base' | 'trades' |
-'ablation'; the reference's
+(NVAE purifier); experiment 'gender' (ResNet-50, 256x256) with 'base' | 'trades' | 'ablation' | 'ours' (e4e + StyleGAN2
+purifier); experiment 'cars' (ResNeXt-50, 128x128) with 'base' | 'trades' | 'ablation'; the reference's
 attack sets (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
 Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
 """
@@ -40,8 +40,7 @@ def load(args: Namespace):
         base_classifier = CelebaIdentityClassifier(d_params.classifier_path, args.device)
         hl_instance = NVAEDefenseModel
     elif args.experiment == 'gender':
-        # ResNet-50 classifier (load_defense.py:27-41): built for defense_type base / trades / ablation; the e4e +
-        # StyleGAN2 purifier of 'ours' is a next row (its constructor raises NotImplementedError)
+        # ResNet-50 classifier + e4e / StyleGAN2 purifier (load_defense.py:27-41)
         args.image_size = 256
         args.attacks = {
             'deepfool': DeepFool(num_classes=2, overshoot=0.01, max_iter=1024),

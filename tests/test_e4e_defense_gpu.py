@@ -73,3 +73,59 @@ def test_e4e_defender_matches_oracle(precision, tol):
     assert eng.dx.abs().max().item() == 0.0
     l1, _ = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, x.repeat_interleave(rep, dim=0), [1.0] * gspec.n_latent, z, 32)
     assert (eng.logits.view(rows, -1).cpu() - l1).abs().max().item() < tol * max(1.0, l1.abs().max().item())
+
+
+def test_e4e_defender_through_the_reference_api(tmp_path):
+    """experiment 'gender', defense_type 'ours' through load(args) (src/experiments/load_defense.py:27-41,124-133): checkpoint
+    layouts of loading_utils.py:10-16,37-48 (pSp: 'state_dict' with encoder./decoder. prefixes, 'latent_avg', 'opts'), EoT
+    wrapper, autograd to the input, get_purified, purify in the normalised domain, mutable interpolation_alphas"""
+    from argparse import Namespace
+    import yaml
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    _, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(dry_run=True, device='cpu')
+    ck = {'state_dict': {**{'encoder.' + k: v for k, v in esd.items()}, **{'decoder.' + k: v for k, v in gsd.items()}},
+          'latent_avg': avg, 'opts': {'stylegan_size': gspec.size, 'start_from_latent_avg': True, 'encoder_type': 'Encoder4Editing'}}
+    torch.save(ck, tmp_path / 'e4e.pt')
+    torch.save({'state_dict': csd}, tmp_path / 'resnet.pt')
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(tmp_path / 'resnet.pt'), 'autoencoder_path': str(tmp_path / 'e4e.pt'),
+                        'interpolation_alphas': [a / 0.5 for a in alphas], 'alpha_attenuation': 0.5, 'initial_noise_eps': 0.0,
+                        'gaussian_blur_input': False}, f)
+    eot = 3
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=eot, device=DEV))
+    gen = torch.Generator().manual_seed(4)
+    x = torch.rand(1, 3, 64, 64, generator=gen)
+    z = torch.randn(eot, gspec.n_latent, gspec.style_dim, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    logits, purified = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, xr.repeat(eot, 1, 1, 1), alphas, z, 64)
+    mean = logits.mean(dim=0, keepdim=True)
+    (gx,) = torch.autograd.grad(mean[0, 1], [xr])
+
+    model.model.fixed_noise([z.to(DEV)], None)
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    assert out.shape == (1, 2)
+    assert (out.detach().cpu() - mean.detach()).abs().max().item() < 1e-3
+    (g,) = torch.autograd.grad(out[0, 1], [xd])
+    rel = ((g.cpu() - gx).double().norm() / gx.double().norm()).item()
+    print(f'e4e defender API: EoT-{eot} logits err {(out.detach().cpu() - mean.detach()).abs().max().item():.2e}, input-grad relL2 {rel:.2e}')
+    assert rel < 3e-2
+
+    # get_purified: the de-normalised reconstruction of a single draw; purify: the same in the normalised domain
+    model.model.fixed_noise([z[:1].to(DEV)], None)
+    p = model.get_purified(x.to(DEV))
+    assert p.shape == (1, 3, 64, 64) and (p.cpu() - purified[:1].detach()).abs().max().item() < 1e-3
+    pn = model.model.purify(x.to(DEV) * 2 - 1)
+    assert (pn.cpu() - (purified[:1].detach() * 2 - 1)).abs().max().item() < 2e-3
+
+    # alpha learning overwrites the list in place (src/experiments/alpha_learning/common_utils.py:88)
+    model.model.interpolation_alphas[:] = [0.0] * gspec.n_latent
+    l0, _ = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, x, [0.0] * gspec.n_latent, z[:1], 64)
+    assert (model.model(x.to(DEV)).cpu() - l0).abs().max().item() < 1e-3
+    model.model.fixed_noise(None, None)
+    a, b = model(x.to(DEV)), model(x.to(DEV))            # alpha = 0: no randomness left
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        from gen_adversarial_amd.defenses.ours.models import E4EStyleGanDefenseModel
+        E4EStyleGanDefenseModel(model.model.classifier, str(tmp_path / 'e4e.pt'), [0.1] * 3, device=DEV)

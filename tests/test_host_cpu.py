@@ -135,11 +135,13 @@ def test_no_cpu_fallback():
     cfg = dict(ASSUMED_NVAE_CONFIG)
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         Engine({}, cfg, ASSUMED_NVAE_RESOLUTION, {}, build_vgg_spec(100, 8), rows=1, rep=1, alphas=[0.0] * 24, device='cpu')
-    from gen_adversarial_amd.defenses.ours.models import CelebaIdentityClassifier, E4EStyleGanDefenseModel
+    from gen_adversarial_amd.defenses.ours.models import CelebaIdentityClassifier, TransStyleGanDefenseModel
     with pytest.raises(RuntimeError, match='GPU only'):
         CelebaIdentityClassifier('/nonexistent', 'cpu')
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        Engine.bare(2, device='cpu')
     with pytest.raises(NotImplementedError):
-        E4EStyleGanDefenseModel()
+        TransStyleGanDefenseModel()
 
 
 def test_pgd_step_and_protocol_on_a_toy_net():

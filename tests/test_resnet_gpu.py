@@ -109,7 +109,7 @@ def test_gender_classifier_api(tmp_path):
     (g,) = torch.autograd.grad(out[:, 1].sum(), [xd])
     assert torch.isfinite(g).all() and g.abs().max().item() > 0
     assert model.get_purified(x) is x
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                  # 'ours' = the e4e defender (tests/test_e4e_defense_gpu.py): needs its checkpoint
         load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=1, device=DEV))
 
 
