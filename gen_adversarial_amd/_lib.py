@@ -52,7 +52,8 @@ class DwDesc(C.Structure):
 
 
 class ReduceDesc(C.Structure):
-    _fields_ = [('a', fp), ('b', fp), ('out', fp), ('N', i32), ('P', i32), ('C', i32), ('scale', f32)]
+    _fields_ = [('a', fp), ('b', fp), ('out', fp), ('N', i32), ('P', i32), ('C', i32), ('scale', f32),
+                ('ws', fp), ('ws_floats', C.c_long)]
 
 
 class SeExciteDesc(C.Structure):

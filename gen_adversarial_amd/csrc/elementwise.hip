@@ -34,6 +34,45 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
     }
 }
 
+// Two-stage variant for long rows: block = (row, 64-channel chunk, pixel segment); ql channel-quad lanes x 256/ql pixel
+// lanes; partial sums go to ws[(n*S + seg)*C + c] and are added in segment order by the second kernel (deterministic).
+__global__ void __launch_bounds__(256) rowchan_reduce_split_kernel(const ga_rowchan_reduce_desc d, const int nchunks, const int ql,
+                                                                   const int S, const int seg_len) {
+    __shared__ floatx4 part[256];
+    const int tid = threadIdx.x, c4 = tid % ql, pl = tid / ql, PL = 256 / ql;
+    int bi = blockIdx.x;
+    const int seg = bi % S; bi /= S;
+    const int chunk = bi % nchunks, n = bi / nchunks;
+    const int c = chunk * 64 + 4 * c4;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < d.C) {
+        const float* a = d.a + (size_t)n * d.P * d.C + c;
+        const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
+        const int p1 = min(d.P, (seg + 1) * seg_len);
+        for (int p = seg * seg_len + pl; p < p1; p += PL) {
+            floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+            if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+            acc += v;
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int st = PL >> 1; st > 0; st >>= 1) {
+        if (pl < st) part[tid] += part[tid + st * ql];
+        __syncthreads();
+    }
+    if (pl == 0 && c < d.C) *reinterpret_cast<floatx4*>(d.ws + ((size_t)n * S + seg) * d.C + c) = part[tid];
+}
+
+__global__ void __launch_bounds__(256) rowchan_reduce_final_kernel(const ga_rowchan_reduce_desc d, const int S) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)d.N * d.C) return;
+    const long n = i / d.C; const int c = (int)(i % d.C);
+    float acc = 0.f;
+    for (int sgm = 0; sgm < S; ++sgm) acc += d.ws[((size_t)n * S + sgm) * d.C + c];
+    d.out[i] = acc * d.scale;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // SE excite: relu(linear_1) -> sigmoid(linear_2) (architecture.py:57-58) and its backward.  One block per row.
 // ---------------------------------------------------------------------------------------------------------------
@@ -928,6 +967,24 @@ extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!aligned16(d->a) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
     const int nchunks = (d->C + 63) / 64;
+    if (d->ws && d->P >= 4096 && d->N * nchunks < 1024) {
+        if (!aligned16(d->ws)) return GA_E_ALIGN;
+        long S = d->ws_floats / ((long)d->N * d->C);
+        const long want = 2048 / ((long)d->N * nchunks);                 // ~8 workgroups per CU
+        if (S > want) S = want;
+        if (S > (d->P + 1023) / 1024) S = (d->P + 1023) / 1024;          // >= 1024 pixels per segment
+        if (S >= 2) {
+            const int q = d->C >= 64 ? 16 : d->C / 4;
+            int ql = 1;
+            while (ql < q) ql <<= 1;
+            const int seg_len = (int)((d->P + S - 1) / S);
+            hipLaunchKernelGGL(rowchan_reduce_split_kernel, dim3((unsigned)(d->N * nchunks * S)), dim3(256), 0, (hipStream_t)s, *d,
+                               nchunks, ql, (int)S, seg_len);
+            const long total = (long)d->N * d->C;
+            hipLaunchKernelGGL(rowchan_reduce_final_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, *d, (int)S);
+            return check_launch();
+        }
+    }
     hipLaunchKernelGGL(rowchan_reduce_kernel, dim3(d->N * nchunks), dim3(256), 0, (hipStream_t)s, *d, nchunks);
     return check_launch();
 }

@@ -244,4 +244,7 @@ class StyleGanBuilder:
     def _reduce(self, name, a, b, out, n, p, c):
         r = L.ReduceDesc()
         r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(a), _ptr(b), _ptr(out), n, p, c, 1.0
+        if p >= 4096:                                    # long rows: split the pixels over workgroups (two-stage reduction)
+            ws = self.scratch((256 * n * c,), 'sg.reduce_ws')
+            r.ws, r.ws_floats = _ptr(ws), ws.numel()
         self.bwd.add(r, name)

@@ -119,10 +119,14 @@ int ga_dwconv5(const ga_dwconv5_desc* d, void* stream);
 /* ------------------------------------------------------------------------------------------------------------------
  * Squeeze-and-excite (architecture.py:37-61) split into its reduction, its two tiny FCs and the residual merge.
  * ------------------------------------------------------------------------------------------------------------------ */
-/* out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)      (squeeze: scale=1/HW; d(gate): b = t, scale = 0.1) */
+/* out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)      (squeeze: scale=1/HW; d(gate): b = t, scale = 0.1)
+ * ws (optional, ws_floats >= 2*N*C): workspace for a two-stage reduction — the pixels of a row are split over up to
+ * ws_floats / (N*C) workgroups and the partial sums added in a fixed order (StyleGAN2 style gradients: 1024^2 pixels, 32
+ * channels, a handful of rows).  Without it one workgroup per (row, 64 channels) walks all P pixels. */
 typedef struct ga_rowchan_reduce_desc {
     const float* a; const float* b; float* out;
     int N, P, C; float scale;
+    float* ws; long ws_floats;
 } ga_rowchan_reduce_desc;
 int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* stream);
 

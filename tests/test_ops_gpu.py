@@ -839,3 +839,25 @@ def test_plan_replay_matches_direct_calls():
     assert y2.abs().max().item() == 0.0
     ms, conv_ms, nconv = p.time(torch.cuda.current_stream().cuda_stream, iters=2, per_conv=True)
     assert ms > 0 and nconv == 1 and conv_ms > 0
+
+
+@pytest.mark.parametrize('N,P,C,with_b', [(3, 5000, 32, True), (2, 16384, 4, True), (2, 4100, 96, False), (1, 70000, 64, True)])
+def test_rowchan_reduce_two_stage(N, P, C, with_b):
+    """long rows (StyleGAN2 style gradients): pixels split over workgroups through a workspace; deterministic"""
+    gen = torch.Generator().manual_seed(N * 1000 + C)
+    a = torch.randn(N, P, C, generator=gen).to(DEV)
+    b = torch.randn(N, P, C, generator=gen).to(DEV) if with_b else None
+    out = torch.zeros(N, C, device=DEV)
+    ws = torch.zeros(64 * N * C, device=DEV)
+    d = L.ReduceDesc()
+    d.a, d.b, d.out, d.N, d.P, d.C, d.scale = a.data_ptr(), (b.data_ptr() if with_b else None), out.data_ptr(), N, P, C, 0.5
+    d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    L.run(d, torch.cuda.current_stream().cuda_stream)
+    ref = 0.5 * ((a * b) if with_b else a).double().sum(dim=1)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    first = out.clone()
+    L.run(d, torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(first, out)
+    d.ws, d.ws_floats = None, 0                              # single-stage path: same sum up to rounding
+    L.run(d, torch.cuda.current_stream().cuda_stream)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
