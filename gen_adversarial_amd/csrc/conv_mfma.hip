@@ -450,6 +450,34 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     if (d.addend && d.ldadd < d.Cout) return GA_E_BADARG;
     if (d.addend2 && d.ldadd2 < d.Cout) return GA_E_BADARG;
     if (d.dact_x && d.lddact < d.Cout) return GA_E_BADARG;
+    // Rows are independent: a tensor beyond the fast loader's 31-bit byte offsets (2 GB; StyleGAN2's 1024^2 x 32-channel maps
+    // at a few dozen rows) is convolved in sub-batches of rows that fit, each an ordinary launch on the same stream.
+    {
+        const long row_x = (long)d.Hi * d.Wi * d.ldx * 4, row_x2 = d.C2 > 0 ? (long)d.Hi * d.Wi * d.ldx2 * 4 : 0;
+        const long row_max = row_x > row_x2 ? row_x : row_x2;
+        const long lim = 0x7fffff00L;
+        if (d.N > 1 && row_max * d.N >= lim && row_max < lim) {
+            const int sub = (int)((lim - 1) / row_max);
+            for (int n0 = 0; n0 < d.N; n0 += sub) {
+                ga_conv_desc s = d;
+                s.N = d.N - n0 < sub ? d.N - n0 : sub;
+                const size_t pin = (size_t)n0 * d.Hi * d.Wi, pout = (size_t)n0 * d.Ho * d.Wo;
+                s.x = d.x + pin * d.ldx;
+                if (d.x2) s.x2 = d.x2 + pin * d.ldx2;
+                s.y = d.y + pout * d.ldy;
+                if (d.addend && !d.addend_bcast_n) s.addend = d.addend + pout * d.ldadd;
+                if (d.addend2) s.addend2 = d.addend2 + pout * d.ldadd2;
+                if (d.dact_x) s.dact_x = d.dact_x + pout * d.lddact;
+                if (d.pro_scale && d.pro_per_row) {
+                    s.pro_scale = d.pro_scale + (size_t)n0 * d.C1;
+                    s.pro_shift = d.pro_shift + (size_t)n0 * d.C1;
+                }
+                const int rc = ga_conv2d(&s, stream_);
+                if (rc != GA_OK) return rc;
+            }
+            return GA_OK;
+        }
+    }
     if ((long)d.N * d.Ho * d.Wo > 0x7fffffffL) return GA_E_UNSUPPORTED;
     if ((long)d.KH * d.KW * (d.C1 + d.C2) > 0x7fffffffL) return GA_E_UNSUPPORTED;
     const long M = (long)d.N * d.Ho * d.Wo;

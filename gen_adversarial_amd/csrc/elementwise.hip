@@ -539,6 +539,11 @@ __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = g[e] * act_bwd(u[e], d.act) * sc[e];
             *reinterpret_cast<floatx4*>(d.dt + i * 4) = o;
+            if (d.dt_planes[0]) {
+                const int h = p / d.W, w = p - h * d.W, H2 = (d.P / d.W) >> 1, W2 = d.W >> 1;
+                float* pl = d.dt_planes[(h & 1) * 2 + (w & 1)];
+                *reinterpret_cast<floatx4*>(pl + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * d.C + 4 * q) = o;
+            }
         }
     }
 }
@@ -1096,6 +1101,10 @@ extern "C" int ga_modout(const ga_modout_desc* d, void* s) {
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && !d->out) return GA_E_BADARG;
     if (d->backward && (!d->dout || !d->dt)) return GA_E_BADARG;
+    if (d->backward && d->dt_planes[0]) {
+        if (!d->dt_planes[1] || !d->dt_planes[2] || !d->dt_planes[3]) return GA_E_BADARG;
+        if (d->W <= 0 || d->W % 2 || d->P % d->W || (d->P / d->W) % 2) return GA_E_BADARG;
+    }
     const long total4 = (long)d->N * d->P * (d->C / 4);
     hipLaunchKernelGGL(modout_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();

@@ -17,7 +17,8 @@ the OUTPUT channels in the tail pass (folding.fold_styled_conv).  Forward / back
   dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d, ga_se_apply (row scale, accumulating into x.g)
   dw_latent += modulation^T ds                  ga_conv2d 1x1
 Up-sampling layer: transposed conv + blur = one 6x6 / stride-2 transposed conv (folding.upsample_conv_weights): four 3x3
-parity convs + ga_interleave2 forward, one 6x6 / 2 conv backward.  ToRGB skip: ga_up2_blur.
+parity convs + ga_interleave2 forward; backward the four parity adjoints over the de-interleaved cotangent (written by
+ga_modout beside the interleaved one).  ToRGB skip: ga_up2_blur.
 """
 from __future__ import annotations
 
@@ -57,7 +58,7 @@ class StyleGanBuilder:
             f = F.fold_styled_conv(sd, spec, noise, cout_pad=co)
             if spec.upsample:
                 f.update(F.upsample_conv_weights(f.pop('w64')))
-                f.pop('w'), f.pop('w_bwd')
+                f.pop('w'), f.pop('w_bwd'), f.pop('up_bwd')
             f.pop('w64', None)
             return f
         wts = self.devd(f'sg.{p}.{spec.res}.{nkey}', fold)
@@ -109,11 +110,19 @@ class StyleGanBuilder:
             b = L.ModoutDesc()
             b.t, b.scale, b.add, b.dout, b.dt = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.g), _ptr(t.g)
             b.N, b.P, b.C, b.act, b.backward = R, P, co, act, 1
+            planes = []
+            if spec.upsample:                                    # dt also de-interleaved: operands of the parity adjoints
+                planes = [self.scratch((R, rin, rin, co), f'sg.up{a}{c}') for a in (0, 1) for c in (0, 1)]
+                b.W = spec.res
+                for i, pl in enumerate(planes):
+                    b.dt_planes[i] = _ptr(pl)
             self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
             dxm = self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
-            if spec.upsample:                                    # adjoint of (transposed conv + blur): one 6x6 / 2 conv
-                self.conv(self.bwd, f'{p}.conv^T', t.g, wts['up_bwd'], dxm, K=6, sn=2, pad=2)
+            if spec.upsample:                                    # adjoint of (transposed conv + blur): sum of the parity adjoints
+                for i, pl in enumerate(planes):
+                    self.conv(self.bwd, f'{p}.conv^T[{i >> 1}{i & 1}]', pl, wts[f'up_bwd{i >> 1}{i & 1}'], dxm, K=3, pad=1,
+                              addend=(dxm if i else None))
             else:
                 self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
             self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, Pin, spec.cin)

@@ -405,8 +405,10 @@ def upsample_conv_weights(w: torch.Tensor) -> dict:
         G[d, e] = sum_{i,j} W[i, j] K[i + 1 - d, j + 1 - e],   d, e in [-2, 3]      (K = outer(k, k) / 16, k = [1,3,3,1])
         out[2U+a, 2V+b] = sum_{dy,dx in {-1,0,1}} z[U+dy, V+dx] G[a - 2 dy, b - 2 dx]
     i.e. four ordinary 3x3 / pad 1 convolutions over the low-resolution input, one per output parity (a, b), and — for the
-    backward-to-input — one 6x6 / stride 2 / pad 2 convolution over the high-resolution cotangent.
-    w: [Cout, Cin, 3, 3] (already scaled).  Returns {'up{a}{b}': [Cout][9*Cin], 'up_bwd': [Cin][36*Cout]}."""
+    backward-to-input — either one 6x6 / stride 2 / pad 2 convolution over the high-resolution cotangent ('up_bwd') or the
+    sum of the four parity convs' adjoints over the de-interleaved cotangent ('up_bwd{a}{b}': 3x3 / pad 1, the form the engine
+    uses: 36 taps exceed the split-bf16 kernel's tap mask, 4 x 9 do not).
+    w: [Cout, Cin, 3, 3] (already scaled).  Returns {'up{a}{b}': [Cout][9*Cin], 'up_bwd{a}{b}': [Cin][9*Cout], 'up_bwd': [Cin][36*Cout]}."""
     co, ci = w.shape[:2]
     k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=torch.float64)
     K = torch.outer(k1, k1) / 16.0
@@ -424,6 +426,7 @@ def upsample_conv_weights(w: torch.Tensor) -> dict:
                 for kx in range(3):
                     wp[:, :, ky, kx] = G[:, :, a - 2 * (ky - 1) + 2, b - 2 * (kx - 1) + 2]
             out[f'up{a}{b}'] = f32(conv_fwd_layout(wp))
+            out[f'up_bwd{a}{b}'] = f32(conv_bwd_layout(wp))        # adjoint of the parity conv: over the de-interleaved cotangent
     out['up_bwd'] = f32(conv_fwd_layout(G.permute(1, 0, 2, 3)))
     return out
 

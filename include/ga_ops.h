@@ -247,7 +247,10 @@ int ga_unary(const ga_unary_desc* d, void* stream);
  * t, out, dout, dt: [N,P,C]; scale: [N,C]; add: [P,C] (noise strength * noise[p] + bias[c], row independent). C % 4 == 0. */
 typedef struct ga_modout_desc {
     const float* t; const float* scale; const float* add; float* out; const float* dout; float* dt;
-    int N, P, C; int act; int backward; int _reserved;
+    int N, P, C; int act; int backward;
+    int W;                    /* row width of the P = H*W pixels; only read when dt_planes is used */
+    float* dt_planes[4];      /* backward, optional: dt is ALSO written de-interleaved, pixel (h, w) -> plane (h&1)*2 + (w&1) at
+                                 [n, h/2, w/2, C] — the operands of the up-sampling layer's four parity backward convs */
 } ga_modout_desc;
 int ga_modout(const ga_modout_desc* d, void* stream);
 

@@ -861,3 +861,33 @@ def test_rowchan_reduce_two_stage(N, P, C, with_b):
     d.ws, d.ws_floats = None, 0                              # single-stage path: same sum up to rounding
     L.run(d, torch.cuda.current_stream().cuda_stream)
     assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_conv_beyond_2gb_runs_in_row_sub_batches():
+    """an input past the fast loader's 31-bit byte offsets (StyleGAN2's 1024^2 maps at a few dozen rows) is convolved in
+    sub-batches of rows: same numbers as one launch per row"""
+    N, H, C, Co = 3, 1024, 192, 8                                   # 3 x 1024^2 x 192 x 4 B = 2.4 GB
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(N, H, H, C, device=DEV, generator=gen)
+    w = (torch.randn(Co, C, device=DEV, generator=gen) / C ** 0.5).contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    sc = (1.0 + 0.1 * torch.randn(N, C, device=DEV, generator=gen)).contiguous()
+    sh = torch.zeros(N, C, device=DEV)
+    add = torch.randn(N, H, H, Co, device=DEV, generator=gen)
+
+    def run(n0, n, out):
+        d = L.ConvDesc()
+        d.x, d.ldx, d.C1, d.w, d.w_hi, d.w_lo = x[n0:].data_ptr(), C, C, w.data_ptr(), hi.data_ptr(), lo.data_ptr()
+        d.pro_scale, d.pro_shift, d.pro_per_row = sc[n0:].data_ptr(), sh[n0:].data_ptr(), 1
+        d.y, d.ldy, d.Cout, d.addend, d.ldadd = out[n0:].data_ptr(), Co, Co, add[n0:].data_ptr(), Co
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad = n, H, H, H, H, 1, 1, 1, 1, 0
+        L.run(d, torch.cuda.current_stream().cuda_stream)
+
+    whole, rows = torch.zeros(N, H, H, Co, device=DEV), torch.zeros(N, H, H, Co, device=DEV)
+    run(0, N, whole)
+    for n in range(N):
+        run(n, 1, rows)
+    assert torch.equal(whole, rows)
+    ref = torch.einsum('nhc,oc->nho', (x[:, 500, :64] * sc[:, None, :]).double(), w.double()) + add[:, 500, :64].double()
+    assert (whole[:, 500, :64].double() - ref).abs().max().item() < 1e-3
