@@ -34,9 +34,23 @@ def test_bad_descriptors_are_rejected_without_a_gpu():
                      (L.DmlDesc(), L.lib.ga_dml_mean), (L.MaxpoolDesc(), L.lib.ga_maxpool2), (L.ImageIoDesc(), L.lib.ga_image_io),
                      (L.BlurDesc(), L.lib.ga_gauss_blur), (L.Interleave2Desc(), L.lib.ga_interleave2),
                      (L.Maxpool3s2Desc(), L.lib.ga_maxpool3s2), (L.AvgpoolActDesc(), L.lib.ga_avgpool_act),
-                     (L.GconvDesc(), L.lib.ga_gconv), (L.PreluDesc(), L.lib.ga_prelu)):
+                     (L.GconvDesc(), L.lib.ga_gconv), (L.PreluDesc(), L.lib.ga_prelu), (L.UnaryDesc(), L.lib.ga_unary),
+                     (L.ModoutDesc(), L.lib.ga_modout), (L.Up2BlurDesc(), L.lib.ga_up2_blur),
+                     (L.LatentMixDesc(), L.lib.ga_latent_mix), (L.PoolDenormDesc(), L.lib.ga_pool_denorm)):
         assert fn(C.byref(desc), None) == -1
     assert L.lib.ga_plan_run(None, 0, None, None) == -1
+    assert L.lib.ga_pixelnorm(None, None, 4, 512, None) == -1
+    m = L.ModoutDesc()                            # StyleGAN2 tail: channel count must be a multiple of 4 lanes
+    m.t = m.out = 16
+    m.N, m.P, m.C = 1, 4, 6
+    assert L.lib.ga_modout(C.byref(m), None) == -3
+    m.C, m.backward, m.dout, m.dt = 8, 1, 16, 16    # de-interleaved cotangent planes: all four or none, even H and W
+    m.dt_planes[0] = 16
+    assert L.lib.ga_modout(C.byref(m), None) == -1
+    p = L.PoolDenormDesc()
+    p.x = p.y = 16
+    p.N, p.H, p.W, p.k, p.ld = 1, 3, 4, 2, 8      # odd height cannot be written in space-to-depth form
+    assert L.lib.ga_pool_denorm(C.byref(p), None) == -3
     d = L.DwDesc()
     d.x = d.w = d.y = 16
     d.N = d.H = d.W = 1
