@@ -154,7 +154,7 @@ class PixelnormDesc(C.Structure):
 
 class LatentMixDesc(C.Structure):
     _fields_ = [('codes', fp), ('avg', fp), ('styles', fp), ('alpha', fp), ('out', fp), ('dout', fp), ('dcodes', fp),
-                ('R', i32), ('J', i32), ('D', i32), ('backward', i32)]
+                ('R', i32), ('J', i32), ('D', i32), ('backward', i32), ('rep', i32), ('_reserved', i32)]
 
 
 class PoolDenormDesc(C.Structure):

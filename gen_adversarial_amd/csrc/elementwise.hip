@@ -609,15 +609,21 @@ __global__ void __launch_bounds__(256) pixelnorm_kernel(const float* __restrict_
 
 __global__ void __launch_bounds__(256) latent_mix_kernel(const ga_latent_mix_desc d, const long total4) {
     const int D4 = d.D / 4;
+    const int rep = d.rep > 1 ? d.rep : 1;
+    const long row4 = (long)d.J * D4;                                  // quads per row
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const int q = (int)(i % D4); const int j = (int)((i / D4) % d.J);
         const float a = d.alpha[j];
-        if (!d.backward) {
-            floatx4 c = ld4(d.codes + i * 4);
+        if (!d.backward) {                                             // i runs over the R output rows
+            const long r = i / row4;
+            floatx4 c = ld4(d.codes + ((r / rep) * row4 + (i - r * row4)) * 4);
             if (d.avg) c += ld4(d.avg + ((size_t)j * d.D + 4 * q));
             *reinterpret_cast<floatx4*>(d.out + i * 4) = (1.0f - a) * c + a * ld4(d.styles + i * 4);
-        } else {
-            *reinterpret_cast<floatx4*>(d.dcodes + i * 4) = (1.0f - a) * ld4(d.dout + i * 4);
+        } else {                                                       // i runs over the R / rep code rows
+            const long r0 = i / row4, off = i - r0 * row4;
+            floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < rep; ++k) acc += ld4(d.dout + ((r0 * rep + k) * row4 + off) * 4);
+            *reinterpret_cast<floatx4*>(d.dcodes + i * 4) = (1.0f - a) * acc;
         }
     }
 }
@@ -1135,7 +1141,8 @@ extern "C" int ga_latent_mix(const ga_latent_mix_desc* d, void* s) {
     if (d->D % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && (!d->codes || !d->styles || !d->out)) return GA_E_BADARG;
     if (d->backward && (!d->dout || !d->dcodes)) return GA_E_BADARG;
-    const long total4 = (long)d->R * d->J * (d->D / 4);
+    if (d->rep > 1 && d->R % d->rep) return GA_E_BADARG;
+    const long total4 = (long)(d->backward && d->rep > 1 ? d->R / d->rep : d->R) * d->J * (d->D / 4);
     hipLaunchKernelGGL(latent_mix_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
 }

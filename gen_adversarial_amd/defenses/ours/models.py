@@ -84,7 +84,7 @@ class E4EStyleGanDefenseModel(MLVGMDefenseModel, torch.nn.Module):
     (alpha per index), decode with the fixed noise buffers, face_pool; (0.5, 0.5) normalisation around the autoencoder.
     One HIP plan pair per (rows, EoT) including the ResNet classifier (engine_stylegan.build_e4e_defense).
     Deliberate differences: generator sizes below 256 px (reduced test checkpoints) skip face_pool instead of being enlarged
-    to 256; the Gaussian-blur pre-processing is not wired for this defender yet."""
+    to 256."""
 
     def __init__(self, classifier: BaseClassificationModel, autoencoder_path: str,
                  interpolation_alphas: tuple, alpha_attenuation: float = 1.0, initial_noise_eps: float = 0.0,
@@ -101,11 +101,11 @@ class E4EStyleGanDefenseModel(MLVGMDefenseModel, torch.nn.Module):
 
     def _make_engine(self, rows: int, rep: int, with_noise: bool = True) -> Engine:
         ae, clf = self.autoencoder, self.classifier.classifier
-        if self.blur_input and with_noise:
-            raise NotImplementedError('apply_gaussian_blur is not wired for the e4e defender yet')
         res = getattr(self, 'image_size', 256)
         eng = Engine.bare(rows, device=self.device, store=self._store, rep=rep, resolution=(3, res, res),
-                          alphas=self.interpolation_alphas, noise_eps=self.eps if with_noise else 0.0)
+                          alphas=self.interpolation_alphas, noise_eps=self.eps if with_noise else 0.0,
+                          blur=self.blur_input and with_noise,
+                          share_encoder=True)      # EoT replicas share the encoder pass whenever no input noise is drawn
         size = ae.decoder_spec.size
         return eng.build_e4e_defense(ae.encoder_sd, ae.encoder_spec, ae.decoder_sd, ae.decoder_spec, ae.latent_avg,
                                      clf.state_dict, clf.spec, pool_to=min(256, size))

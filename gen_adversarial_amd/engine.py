@@ -81,7 +81,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
     @classmethod
     def bare(cls, rows: int, device='cuda:0', precision: str = 'bf16x3', store: Optional[WeightStore] = None,
              dry_run: bool = False, rep: int = 1, resolution=None, alphas: Sequence[float] = (), noise_eps: float = 0.0,
-             need_backward: bool = True) -> "Engine":
+             need_backward: bool = True, blur: bool = False, share_encoder: bool = False) -> "Engine":
         """An engine with empty plans: building blocks that are not yet part of a full defender (the StyleGAN2 layers of
         engine_stylegan.py) are emitted into it by their builders and closed with `finish()`; forward() / backward() then
         replay the plans as for a full engine."""
@@ -94,8 +94,12 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.has_nvae, self.spec, self.vspec, self.resolution = False, None, None, (tuple(resolution) if resolution else None)
         self.rows, self.rep, self.alphas, self.temperature = rows, rep, [float(a) for a in alphas], 1.0
-        self.noise_eps, self.blur = float(noise_eps), False
-        self.share_encoder, self.enc_rows, self.need_backward, self.image_s2d = False, rows, need_backward, False
+        self.noise_eps, self.blur = float(noise_eps), bool(blur)
+        # EoT replicas are identical until randomness enters: without input noise an encoder in front of the first random
+        # draw runs once per image (see Engine.__init__); builders that support it read share_encoder / enc_rows
+        self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0
+        self.enc_rows = rows // rep if self.share_encoder else rows
+        self.need_backward, self.image_s2d = need_backward, False
         self.bytes, self.acts, self.version, self._sampler_descs, self._keep = 0, {}, 0, [], []
         self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None

@@ -196,9 +196,16 @@ class StyleGanBuilder:
         assert (gspec.n_latent, gspec.style_dim) == (J, D), 'encoder and generator disagree on the latent layout'
         assert gspec.size % pool_to == 0 and pool_to % 2 == 0, 'face_pool is built as a k x k mean'
         self.image_s2d = False
-        x0 = self._build_input()
+        x0 = self._build_input()                                               # enc_rows rows (one per image when shared)
         self.vspec = espec
-        codes = self._build_e4e(esd, x0, normalize=True)                       # [R, J*D]; cotangent buffer = self.dlogits
+        # With share_encoder (no input noise) the EoT replicas of an image are the same encoder input: the encoder runs once
+        # per image, latent_mix reads code row r / rep and its adjoint sums the replicas' cotangents.  Same numbers as the
+        # literal x.repeat(eot) path (wrappers.py:20), row for row.
+        self.rows = self.enc_rows
+        try:
+            codes = self._build_e4e(esd, x0, normalize=True)                   # [enc_rows, J*D]; cotangent buffer = self.dlogits
+        finally:
+            self.rows = R
         dcodes = self.dlogits
         self.eps = [self.alloc((R, J, D))]
         styles = self.build_mapping(gsd, self.eps[0].view(R * J, D))
@@ -208,12 +215,13 @@ class StyleGanBuilder:
         latent = Act(self, R, 1, 1, J * D, 'sg.latent')
         mx = L.LatentMixDesc()
         mx.codes, mx.avg, mx.styles, mx.alpha, mx.out = _ptr(codes), _ptr(avg), _ptr(styles), _ptr(self.alpha_dev), _ptr(latent.t)
-        mx.R, mx.J, mx.D, mx.backward = R, J, D, 0
+        mx.R, mx.J, mx.D, mx.backward, mx.rep = R, J, D, 0, R // self.enc_rows
         self.fwd.add(mx, 'latent_mix')
 
         def bwd_mix():
             b = L.LatentMixDesc()
             b.alpha, b.dout, b.dcodes, b.R, b.J, b.D, b.backward = _ptr(self.alpha_dev), _ptr(latent.g), _ptr(dcodes), R, J, D, 1
+            b.rep = R // self.enc_rows
             self.bwd.add(b, 'latent_mix^T')
         self._bwd_steps.append(bwd_mix)
 

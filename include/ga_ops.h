@@ -268,10 +268,13 @@ int ga_pixelnorm(const float* x, float* y, long rows, int C, void* stream);
 /* Latent mixing of the e4e defender (src/defenses/ours/models.py:116-127 + pSp.encode's latent_avg, psp.py:93-103):
  *   forward : out[r, j, :] = (1 - alpha[j]) * (codes[r, j, :] + avg[j, :]) + alpha[j] * styles[r, j, :]
  *   backward: dcodes[r, j, :] = (1 - alpha[j]) * dout[r, j, :]
- * codes / styles / out / dout / dcodes: [R, J, D]; avg: [J, D] or NULL; alpha: [J] (device).  D % 4 == 0. */
+ * styles / out / dout: [R, J, D]; codes / dcodes: [R / max(rep, 1), J, D]; avg: [J, D] or NULL; alpha: [J] (device).  D % 4 == 0. */
 typedef struct ga_latent_mix_desc {
     const float* codes; const float* avg; const float* styles; const float* alpha; float* out;
     const float* dout; float* dcodes; int R, J, D; int backward;
+    int rep;      /* > 1: codes / dcodes have R / rep rows — the encoder ran once per image and its `rep` EoT replicas (consecutive
+                     rows) share the codes; dcodes sums the replicas' cotangents in row order.  0 or 1: one code row per row */
+    int _reserved;
 } ga_latent_mix_desc;
 int ga_latent_mix(const ga_latent_mix_desc* d, void* stream);
 

@@ -40,11 +40,14 @@ def test_mapping_network_matches_oracle():
         assert e < tol * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])
-def test_e4e_defender_matches_oracle(precision, tol):
+@pytest.mark.parametrize('precision,tol,share', [('fp32', 2e-4, False), ('bf16x3', 1e-3, False), ('fp32', 2e-4, True), ('bf16x3', 1e-3, True)])
+def test_e4e_defender_matches_oracle(precision, tol, share):
+    """share: the encoder runs once per image and its EoT replicas read the same codes — compared with the oracle's literal
+    x.repeat(eot) path all the same"""
     from oracle import defender_oracle as D
     rows, rep = 4, 2
-    eng, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(rows, rep, DEV, False, precision)
+    eng, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(rows, rep, DEV, False, precision, share)
+    assert eng.enc_rows == (rows // rep if share else rows)
     gen = torch.Generator().manual_seed(3)
     x = torch.rand(rows // rep, 3, 64, 64, generator=gen)
     z = torch.randn(rows, gspec.n_latent, gspec.style_dim, generator=gen)
@@ -61,7 +64,7 @@ def test_e4e_defender_matches_oracle(precision, tol):
     eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
     eng.backward()
     rel = ((eng.dx.cpu() - gx).double().norm() / gx.double().norm()).item()
-    print(f'e4e defender [{precision}]: {len(eng.fwd)} + {len(eng.bwd)} ops; purified err {e_p:.2e} logits err {e_l:.2e} '
+    print(f'e4e defender [{precision}{", shared encoder" if share else ""}]: {len(eng.fwd)} + {len(eng.bwd)} ops; purified err {e_p:.2e} logits err {e_l:.2e} '
           f'(|logits| {logits.abs().max().item():.2f}); input-grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
     assert e_p < tol and e_l < tol * max(1.0, logits.abs().max().item())
     assert rel < 3e-2

@@ -289,7 +289,7 @@ def test_stylegan_generator_plans_build_without_a_gpu():
     assert sum(n.endswith('skip_upsample') for n in eng.fwd.names) == 3
 
 
-def _small_e4e_defense(rows=2, rep=1, device='cpu', dry_run=True, precision='bf16x3'):
+def _small_e4e_defense(rows=2, rep=1, device='cpu', dry_run=True, precision='bf16x3', share_encoder=False):
     from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
     from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
     from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
@@ -303,7 +303,8 @@ def _small_e4e_defense(rows=2, rep=1, device='cpu', dry_run=True, precision='bf1
     g = torch.Generator().manual_seed(6)
     avg = 0.5 * torch.randn(gspec.n_latent, gspec.style_dim, generator=g)
     alphas = [0.1 * (j % 4) for j in range(gspec.n_latent)]
-    eng = Engine.bare(rows, device=device, dry_run=dry_run, precision=precision, rep=rep, resolution=(3, res, res), alphas=alphas)
+    eng = Engine.bare(rows, device=device, dry_run=dry_run, precision=precision, rep=rep, resolution=(3, res, res), alphas=alphas,
+                      share_encoder=share_encoder)
     eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=32)
     return eng, (esd, espec, gsd, gspec, avg, csd, cspec, alphas)
 
@@ -319,3 +320,8 @@ def test_e4e_defense_plans_build_without_a_gpu():
     assert rorder == sorted(rorder)
     assert not any(n.startswith('sg.mapping') for n in b)          # the mapping network sees noise only: no backward
     assert eng.logits.shape[0] == 2 and eng.eps[0].shape == (2, 10, 128)
+    # EoT replicas share the encoder pass: its ops see one row per image, everything after the latent mixing sees all rows
+    sh, _ = _small_e4e_defense(rows=6, rep=3, share_encoder=True)
+    n_of = {n: d.N for d, n in zip(sh.fwd.descs, sh.fwd.names) if hasattr(d, 'N')}
+    assert n_of['e4e.input.conv'] == 2 and n_of['conv1.conv'] == 6 and n_of['resnet.conv1'] == 6
+    assert sh.x_in.shape[0] == 2 and sh.dx.shape[0] == 2 and sh.dlogits.shape[0] == 6

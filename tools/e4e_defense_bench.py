@@ -22,7 +22,8 @@ gsd = init_stylegan_state_dict(gspec, 1)
 cspec, csd = build_resnet_spec(2), init_resnet_state_dict(2, 1, 2)
 avg = torch.zeros(gspec.n_latent, gspec.style_dim)
 alphas = [0.3] * gspec.n_latent
-eng = Engine.bare(rows, device='cuda:0', rep=eot, resolution=(3, 256, 256), alphas=alphas)
+share = os.environ.get('GA_SHARE_ENCODER', '1') == '1'          # exact without input noise (the API's default)
+eng = Engine.bare(rows, device='cuda:0', rep=eot, resolution=(3, 256, 256), alphas=alphas, share_encoder=share)
 eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=256)
 print(f'built: {len(eng.fwd)} + {len(eng.bwd)} ops, {eng.bytes / 1e9:.1f} GB engine buffers, {eng.store.bytes / 1e9:.2f} GB weights', flush=True)
 eng.x_in.uniform_()
@@ -37,7 +38,7 @@ s = eng.stream()
 f_ms, fc_ms, fn = eng.fwd.time(s, iters=2, per_conv=True)
 b_ms, bc_ms, bn = eng.bwd.time(s, iters=2, per_conv=True)
 fl = conv_algorithmic_flops(eng.fwd) + conv_algorithmic_flops(eng.bwd)
-print(json.dumps({'rows': rows, 'eot': eot, 'fwd_ms': f_ms, 'bwd_ms': b_ms, 'rows_per_s': rows / (f_ms + b_ms) * 1e3,
+print(json.dumps({'rows': rows, 'eot': eot, 'encoder_shared_by_eot_replicas': bool(eng.share_encoder), 'fwd_ms': f_ms, 'bwd_ms': b_ms, 'rows_per_s': rows / (f_ms + b_ms) * 1e3,
                   'conv_ms': fc_ms + bc_ms, 'conv_tflops': fl / (fc_ms + bc_ms) / 1e9, 'gflop_per_row': fl / rows / 1e9,
                   'gb': eng.bytes / 1e9, 'ops': len(eng.fwd) + len(eng.bwd)}), flush=True)
 
