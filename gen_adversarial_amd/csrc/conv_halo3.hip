@@ -10,6 +10,9 @@
 // and feeds the 9 taps from it: the A fragment of tap (kh, kw) is the same ds_read_b128 at a uniform LDS offset
 // (kh*(Wo+2) + kw) rows further.  Only the weight tile changes per tap (pre-split bf16, plain copies, double-buffered).
 // Same tile order, epilogue, split-K (over channel chunks) and operand layouts as conv_bf3.
+// Wide images (Wo a multiple of 128: the 256^2 .. 1024^2 layers of the e4e encoder and the StyleGAN2 synthesis network): the
+// tile is a 128-pixel SEGMENT of one row and its window 3 x 130 pixels (3x the tile instead of 9x); 13 patch slots per thread
+// instead of 9, hence a second set of instantiations (template parameter RP).
 #include "ga_common.h"
 #include "conv_epilogue.h"
 
@@ -29,8 +32,8 @@ __device__ unsigned long long ga_trace_buf_halo[8 * 8192];
 
 constexpr int HK = 32;          // channels per chunk
 constexpr int LDH = 40;         // bf16 per LDS row (32 + 8 pad = 80 B, conflict-free 16-B fragment reads)
-constexpr int RPMAX = 9;        // patch float4 slots per thread: ceil(288 * 8 / 256)
-constexpr int HALO_PMAX = 288;  // patch pixels a 128-pixel tile may need (8 images of 4x4: 8 * 6 * 6)
+// patch float4 slots per thread (template parameter RP): 9 = ceil(288 * 8 / 256) for tiles of whole rows (at most 288 patch
+// pixels: 8 images of 4x4 -> 8 * 6 * 6), 13 for a row segment (3 * 130 = 390 patch pixels)
 
 // LDS image of the patch: pixel (img, py, px) of a plane at img*IS + py*RS + px*LDH elements.  RS and IS are padded so
 // that tile row r lands on the bank slot of a linear 80-B pitch (80 r mod 256) although the rows of the window are
@@ -38,11 +41,12 @@ constexpr int HALO_PMAX = 288;  // patch pixels a 128-pixel tile may need (8 ima
 // fragment ds_read_b128 then stay conflict-free across row and image boundaries, as in conv_bf3's linear tile.
 struct halo_geom {
     int TH, NI, PH, PW, P;      // rows per image in the tile, images per tile, patch rows / cols per image, patch pixels
+    int TW, wide;               // tile width (= Wo, or 128 for a row segment of a wide image: wide = 1)
     int RS, IS;                 // row / image stride of a patch plane, in bf16 elements
-    fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo;
+    fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo, fd_tw;
 };
 
-template <int WM, int WN, int TM, int TN, int AFF, int ACT>
+template <int WM, int WN, int TM, int TN, int AFF, int ACT, int RPMAX>
 __global__ void __launch_bounds__(256, 2)
 conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C, const int Ktot, const int nkc,
                   const int vec_out, const halo_geom g) {
@@ -75,6 +79,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
     const int HoWo = d.Ho * d.Wo;
     const int n_first = fd_div(m0, g.fd_howo);
     const int y0 = HoWo > BM ? fd_div(m0 - n_first * HoWo, g.fd_wo) : 0;
+    const int x0 = g.wide ? m0 - n_first * HoWo - y0 * d.Wo : 0;       // first column of a row segment
     const int rp = (g.P * 8 + 255) >> 8;                    // patch slots per thread in use (uniform)
 
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
@@ -96,7 +101,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             const int rem = pp - img * g.PH * g.PW;
             const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
             plds[j] = img * g.IS + py * g.RS + px * LDH + 4 * c4;
-            const int n = n_first + img, hi = y0 - 1 + py, wi = px - 1;
+            const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
             if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
                 off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
                 okbits |= 1u << j;
@@ -111,8 +116,8 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
     for (int i = 0; i < TM; ++i) {
         const int o = wm * TM * 32 + i * 32 + lrow;
         const int img = fd_div(o, g.fd_thwo);
-        const int rem = o - img * g.TH * d.Wo;
-        const int y = fd_div(rem, g.fd_wo), x = rem - y * d.Wo;
+        const int rem = o - img * g.TH * g.TW;
+        const int y = fd_div(rem, g.fd_tw), x = rem - y * g.TW;
         fragA[i] = img * g.IS + y * g.RS + x * LDH + 8 * lh;
     }
     int baseB[RB];
@@ -300,16 +305,16 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
     GA_HSTAMP(4)
 }
 
-template <int WM, int WN, int TM, int TN, int AFF, int ACT>
+template <int WM, int WN, int TM, int TN, int AFF, int ACT, int RP>
 static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ktot,
                              int nkc, int vec_out, const halo_geom& g) {
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT, RP>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL((conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, Ktot,
+    hipLaunchKernelGGL((conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, Ktot,
                        nkc, vec_out, g);
 }
 
@@ -318,11 +323,14 @@ static inline int halo_mode(const ga_conv_desc& d) {
 }
 
 // 1 when the descriptor is a 3x3 / stride 1 / pad 1 single-source convolution whose 128-pixel tiles are whole image rows
+// (or whole small images) or 128-pixel segments of one row
 int conv_halo3_supports(const ga_conv_desc& d) {
     if (d.KH != 3 || d.KW != 3 || d.sn != 1 || d.sd != 1 || d.pad != 1 || d.C2 != 0) return 0;
     if (d.Ho != d.Hi || d.Wo != d.Wi || d.C1 % HK != 0) return 0;
     const int HoWo = d.Ho * d.Wo;
-    if (128 % d.Wo != 0 || !(HoWo % 128 == 0 || 128 % HoWo == 0)) return 0;
+    const bool rows = d.Wo < 128 && 128 % d.Wo == 0 && (HoWo % 128 == 0 || 128 % HoWo == 0);   // tiles of whole rows / images
+    const bool segs = d.Wo % 128 == 0;                                                          // tiles = row segments
+    if (!rows && !segs) return 0;
     switch (halo_mode(d)) {
         case 0x00: case 0x01: case 0x02: case 0x03: case 0x04: case 0x10: case 0x11: case 0x20: return 1;
         default: return 0;
@@ -337,22 +345,25 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
     const int nkc = d.C1 / HK;
     const int HoWo = d.Ho * d.Wo;
     halo_geom g;
-    g.TH = HoWo >= BM ? BM / d.Wo : d.Ho;
+    g.wide = d.Wo >= BM ? 1 : 0;
+    g.TW = g.wide ? BM : d.Wo;
+    g.TH = g.wide ? 1 : (HoWo >= BM ? BM / d.Wo : d.Ho);
     g.NI = HoWo >= BM ? 1 : BM / HoWo;
     g.PH = g.TH + 2;
-    g.PW = d.Wo + 2;
+    g.PW = g.TW + 2;
     g.P = g.NI * g.PH * g.PW;
-    if (g.P > HALO_PMAX) return GA_E_UNSUPPORTED;
+    if (g.P > 13 * 32) return GA_E_UNSUPPORTED;
     auto pad_to = [](int bytes, int want_mod256) { return bytes + ((want_mod256 - bytes) % 256 + 256) % 256; };
-    const int rs_bytes = pad_to(g.PW * LDH * 2, (d.Wo * LDH * 2) % 256);
-    const int is_bytes = pad_to(g.PH * rs_bytes, (g.TH * d.Wo * LDH * 2) % 256);
+    const int rs_bytes = pad_to(g.PW * LDH * 2, (g.TW * LDH * 2) % 256);
+    const int is_bytes = pad_to(g.PH * rs_bytes, (g.TH * g.TW * LDH * 2) % 256);
     g.RS = rs_bytes / 2;
     g.IS = is_bytes / 2;
     g.fd_howo = make_fastdiv(HoWo);
     g.fd_wo = make_fastdiv(d.Wo);
     g.fd_phpw = make_fastdiv(g.PH * g.PW);
     g.fd_pw = make_fastdiv(g.PW);
-    g.fd_thwo = make_fastdiv(g.TH * d.Wo);
+    g.fd_thwo = make_fastdiv(g.TH * g.TW);
+    g.fd_tw = make_fastdiv(g.TW);
     if (splits > nkc) return GA_E_UNSUPPORTED;
     const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
     size_t lds = ((size_t)2 * g.NI * g.IS + (size_t)2 * 2 * BN * LDH) * 2;
@@ -360,27 +371,35 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
-#define GA_HALO(A, C) launch_halo_inst<WM, WN, TM, TN, A, C>(d, stream, grid, lds, tilesN, M, Ktot, nkc, vec_out, g)
+    // row-segment tiles (13 patch slots) are instantiated for the prologues the wide layers use: none (backward convs), the
+    // per-channel affine / PReLU (e4e IR units at 256^2 and 128^2) and the per-row style scale (StyleGAN2 modulated convs)
+#define GA_HALO(A, C) launch_halo_inst<WM, WN, TM, TN, A, C, 9>(d, stream, grid, lds, tilesN, M, Ktot, nkc, vec_out, g)
+#define GA_HALO_W(A, C)                                                                                               \
+    if (g.P > 9 * 32) launch_halo_inst<WM, WN, TM, TN, A, C, 13>(d, stream, grid, lds, tilesN, M, Ktot, nkc, vec_out, g);  \
+    else GA_HALO(A, C)
+    if (g.P > 9 * 32 && !(halo_mode(d) == 0x00 || halo_mode(d) == 0x10 || halo_mode(d) == 0x20)) return GA_E_UNSUPPORTED;
     switch (halo_mode(d)) {
-        case 0x00: GA_HALO(0, GA_ACT_NONE); break;
+        case 0x00: GA_HALO_W(0, GA_ACT_NONE); break;
         case 0x01: GA_HALO(0, GA_ACT_SILU); break;
         case 0x02: GA_HALO(0, GA_ACT_ELU); break;
         case 0x03: GA_HALO(0, GA_ACT_RELU); break;
         case 0x04: GA_HALO(0, GA_ACT_LRELU); break;
-        case 0x10: GA_HALO(1, GA_ACT_NONE); break;
-        case 0x11: GA_HALO(1, GA_ACT_SILU); break;
-        case 0x20: GA_HALO(2, GA_ACT_NONE); break;
+        case 0x10: GA_HALO_W(1, GA_ACT_NONE); break;
+        case 0x11: GA_HALO(0 + 1, GA_ACT_SILU); break;
+        case 0x20: GA_HALO_W(2, GA_ACT_NONE); break;
         default: return GA_E_UNSUPPORTED;
     }
+#undef GA_HALO_W
 #undef GA_HALO
     return check_launch();
 }
 
-// tile codes 5 (128 x 128) and 6 (128 x 64) of ga_conv_desc.tile; called by ga_conv2d after validation
+// tile codes 5 (128 x 128), 6 (128 x 64) and 7 (128 x 32) of ga_conv_desc.tile; called by ga_conv2d after validation
 int conv_halo3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
     switch (tile) {
         case 5: return launch_halo<2, 2, 2, 2>(d, stream, vec_out, splits);
         case 6: return launch_halo<4, 1, 1, 2>(d, stream, vec_out, splits);
+        case 7: return launch_halo<4, 1, 1, 1>(d, stream, vec_out, splits);
         default: return GA_E_UNSUPPORTED;
     }
 }

@@ -376,10 +376,10 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             T = d.KH * d.KW * ((d.C1 + d.C2 + 31) // 32)
             best = None
             modes = (1, 0) if d.w_hi else (0,)
-            halo = (5, 6) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
+            halo = (5, 6, 7) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
             for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + (halo if m_ else ())]:
-                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64)}[tile]
-                if bn >= 2 * max(32, d.Cout) and tile != 4:
+                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32)}[tile]
+                if bn >= 2 * max(32, d.Cout) and tile not in (4, 7):
                     continue
                 blocks = -(-M // bm) * -(-d.Cout // bn)
                 for splits in (1, 2, 4, 8, 16, 32):

@@ -82,8 +82,9 @@ typedef struct ga_conv_desc {
     int dact_act;
     int addend_bcast_n;                    /* addend is [Ho,Wo,ldadd], shared by all n */
     int tile;                              /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32 (M x N);
-                                              5 = 128x128, 6 = 128x64 on the halo-staged 3x3 kernel (3x3, stride 1, pad 1,
-                                              C1 % 32 == 0, 128 % Wo == 0, w_hi/w_lo given; GA_E_UNSUPPORTED otherwise) */
+                                              5 = 128x128, 6 = 128x64, 7 = 128x32 on the halo-staged 3x3 kernel (3x3, stride 1,
+                                              pad 1, C1 % 32 == 0, 128 % Wo == 0 or Wo % 128 == 0, w_hi/w_lo given;
+                                              GA_E_UNSUPPORTED otherwise) */
     int splits;                            /* split-K factor (<=1: none); needs ws */
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
     long ws_floats;

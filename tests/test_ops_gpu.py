@@ -203,6 +203,10 @@ def test_conv_bf16x3(N, H, Cin, Cout, K, act, tile):
     (2, 32, 32, 32, 40, 3, False, 5, 1),      # 4 image rows per tile, ReLU
     (1, 64, 64, 32, 32, 2, False, 6, 1),      # 2 image rows per tile, ELU
     (2, 8, 16, 96, 128, 1, True, 5, 3),       # non-square image, three K splits
+    (2, 6, 128, 32, 32, 0, False, 7, 1),      # wide image: the tile is one whole 128-pixel row (3 x 130 window), 128 x 32 tile
+    (1, 5, 256, 64, 64, 0, False, 6, 2),      # row segments: two tiles per row, odd height, two K splits
+    (2, 4, 384, 32, 96, 0, True, 5, 1),       # three segments per row, BN-affine prologue, Cout not a tile multiple
+    (3, 8, 8, 64, 32, 0, False, 7, 1),        # 128 x 32 tile on small images
 ])
 def test_conv_halo3(N, H, W, Cin, Cout, act, affine, tile, splits):
     """halo-staged 3x3 kernel (tile codes 5/6) against torch: forward with the prologue variants it instantiates, and as
@@ -256,10 +260,24 @@ def test_conv_halo3_per_row_prologue():
     wf = fwd_w(w)
     hi = wf.to(torch.bfloat16)
     lo = (wf - hi.float()).to(torch.bfloat16)
-    for tile in (5, 6):
+    for tile in (5, 6, 7):
         y = torch.full((N, H, H, Cout), float('nan'), device=DEV)
         run_conv(nhwc(x), wf, y, 3, pad=1, tile=tile, pro_scale=sc.to(DEV), pro_shift=sh.to(DEV), pro_per_row=1, w_hi=hi, w_lo=lo)
         close(nchw(y), ref, 2e-4, f'halo per-row prologue tile {tile}')
+    # row segments of a wide image (StyleGAN2's modulated convs at 256^2 .. 1024^2): the style scale per (row, channel)
+    N, H, W, Cin, Cout = 3, 3, 256, 32, 32
+    x = g(N, Cin, H, W, seed=5)
+    w = g(Cout, Cin, 3, 3, seed=6, scale=1.0 / np.sqrt(Cin * 9))
+    sc = torch.rand(N, Cin, generator=torch.Generator().manual_seed(7)) + 0.5
+    ref = F.conv2d(x * sc.view(N, Cin, 1, 1), w, None, padding=1)
+    wf = fwd_w(w)
+    hi = wf.to(torch.bfloat16)
+    lo = (wf - hi.float()).to(torch.bfloat16)
+    for tile in (6, 7):
+        y = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+        run_conv(nhwc(x), wf, y, 3, pad=1, tile=tile, pro_scale=sc.to(DEV), pro_shift=torch.zeros(N, Cin, device=DEV), pro_per_row=1,
+                 w_hi=hi, w_lo=lo)
+        close(nchw(y), ref, 2e-4, f'halo per-row prologue, row segments, tile {tile}')
 
 
 @pytest.mark.parametrize('k,bf3', [(3, True), (3, False), (1, True)])
@@ -891,3 +909,16 @@ def test_conv_beyond_2gb_runs_in_row_sub_batches():
     assert torch.equal(whole, rows)
     ref = torch.einsum('nhc,oc->nho', (x[:, 500, :64] * sc[:, None, :]).double(), w.double()) + add[:, 500, :64].double()
     assert (whole[:, 500, :64].double() - ref).abs().max().item() < 1e-3
+
+
+def test_halo_tiles_refuse_unsupported_shapes():
+    """explicit halo tile codes are never silently rerouted: 8-channel image convs, 1x1 convs and wide images with a prologue
+    activation that has no row-segment instantiation are refused"""
+    for (cin, k, w_, act) in ((8, 3, 64, 0), (32, 1, 64, 0), (32, 3, 256, 1)):
+        x = torch.zeros(1, 4, w_, cin, device=DEV)
+        w = torch.zeros(32, k * k * cin, device=DEV)
+        hi = w.to(torch.bfloat16)
+        y = torch.zeros(1, 4, w_, 32, device=DEV)
+        for tile in (5, 6, 7):
+            with pytest.raises(L.GaError):
+                run_conv(x, w, y, k, pad=k // 2, tile=tile, w_hi=hi, w_lo=hi, pro_act=act)
