@@ -132,3 +132,53 @@ def test_e4e_defender_through_the_reference_api(tmp_path):
     with pytest.raises(ValueError):
         from gen_adversarial_amd.defenses.ours.models import E4EStyleGanDefenseModel
         E4EStyleGanDefenseModel(model.model.classifier, str(tmp_path / 'e4e.pt'), [0.1] * 3, device=DEV)
+
+
+def test_fullsize_e4e_defender_properties():
+    """The reference's sizes — IR-SE50 on 256x256, 18 x 512 latents, StyleGAN2 at 1024x1024, face_pool to 256, ResNet-50 — with
+    random weights: too large for the CPU oracle, so size-independent properties: finite outputs in range, EoT replicas with
+    equal noise give bitwise equal rows, the shared-encoder plan equals the literal-repeat plan, the backward pass is linear
+    in its cotangent."""
+    from gen_adversarial_amd.engine import Engine, WeightStore
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    espec, esd = build_e4e_spec(1024), init_e4e_state_dict(1024, 1, 0)
+    gspec = build_stylegan_spec(1024)
+    gsd = init_stylegan_state_dict(gspec, 1)
+    cspec, csd = build_resnet_spec(2), init_resnet_state_dict(2, 1, 2)
+    assert (gspec.n_latent, gspec.style_dim, gspec.convs[-1].cout) == (18, 512, 32)
+    gen = torch.Generator().manual_seed(5)
+    avg = 0.1 * torch.randn(18, 512, generator=gen)
+    alphas = [0.05 * (j % 5) for j in range(18)]
+    store = WeightStore(DEV)
+    rows, rep = 2, 2
+    x = torch.rand(1, 3, 256, 256, generator=gen)
+    z = torch.randn(1, 18, 512, generator=gen).repeat(rows, 1, 1)          # equal noise for both replicas
+    out = {}
+    for share in (False, True):
+        eng = Engine.bare(rows, device=DEV, store=store, rep=rep, resolution=(3, 256, 256), alphas=alphas, share_encoder=share)
+        eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=256)
+        eng.x_in.copy_(x.to(DEV))
+        eng.eps[0].copy_(z.to(DEV))
+        eng.forward()
+        logits, purified = eng.logits.view(rows, -1).clone(), eng.purified_nchw()
+        assert torch.isfinite(logits).all() and torch.isfinite(purified).all() and purified.shape == (rows, 3, 256, 256)
+        assert torch.equal(logits[0], logits[1]) and torch.equal(purified[0], purified[1])
+        grads = []
+        a = torch.randn(rows, 2, generator=gen).to(DEV)
+        b = torch.randn(rows, 2, generator=gen).to(DEV)
+        for c in (a, b, a + b):
+            eng.dlogits.view(rows, -1).copy_(c)
+            eng.backward()
+            grads.append(eng.dx.clone())
+        scale = grads[2].abs().max().item()
+        lin = (grads[2] - grads[0] - grads[1]).abs().max().item()
+        print(f'full-size e4e defender (share={share}): logits {logits[0].tolist()}, |dx| {scale:.2e}, backward linearity {lin:.2e}')
+        assert torch.isfinite(grads[2]).all() and scale > 0 and lin < 1e-4 * scale
+        out[share] = (logits, purified, grads[0], a)
+        del eng
+        torch.cuda.empty_cache()
+    l0, p0, _, _ = out[False]
+    l1, p1, _, _ = out[True]
+    assert (l0 - l1).abs().max().item() < 1e-4 * max(1.0, l0.abs().max().item()) and (p0 - p1).abs().max().item() < 1e-4

@@ -15,6 +15,13 @@ s = eng.stream()
 f0, fc0, _ = eng.fwd.time(s, iters=3, per_conv=True); b0, bc0, _ = eng.bwd.time(s, iters=3, per_conv=True)
 print(f'before: fwd {f0:.2f} (conv {fc0:.2f})  bwd {b0:.2f} (conv {bc0:.2f})', flush=True)
 fresh = len(sys.argv) > 3 and sys.argv[3] == 'fresh'
-cache = eng.autotune(cache={} if fresh else None, reps=5, save=out, verbose=True)     # default: add missing shapes
+start = {} if fresh else None
+if len(sys.argv) > 3 and sys.argv[3] == 'retune3x3':       # new halo tile codes: time this engine's 3x3 / stride-1 shapes again
+    from gen_adversarial_amd.engine_core import conv_key, tune_cache
+    start = dict(tune_cache())
+    for d in eng._conv_descs():
+        if d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0:
+            start.pop(conv_key(d), None)
+cache = eng.autotune(cache=start, reps=5, save=out, verbose=True)     # default: add missing shapes
 f1, fc1, _ = eng.fwd.time(s, iters=3, per_conv=True); b1, bc1, _ = eng.bwd.time(s, iters=3, per_conv=True)
 print(f'after : fwd {f1:.2f} (conv {fc1:.2f})  bwd {b1:.2f} (conv {bc1:.2f})  entries {len(cache)}')
