@@ -182,3 +182,45 @@ def test_fullsize_e4e_defender_properties():
     l0, p0, _, _ = out[False]
     l1, p1, _, _ = out[True]
     assert (l0 - l1).abs().max().item() < 1e-4 * max(1.0, l0.abs().max().item()) and (p0 - p1).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('noise_eps,blur', [(4.0, False), (0.0, True)])
+def test_e4e_defender_preprocessing_configs(tmp_path, noise_eps, blur):
+    """configs/ours_*_noise_gender.yaml (initial_noise_eps 4.0: the encoder can no longer be shared by the EoT replicas) and
+    ours_*_blur_gender.yaml (gaussian_blur_input) through load(args), against the oracle's pre-processing helpers
+    (abstract_models.py:129-159) in front of its e4e defender"""
+    from argparse import Namespace
+    import yaml
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    _, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(dry_run=True, device='cpu')
+    ck = {'state_dict': {**{'encoder.' + k: v for k, v in esd.items()}, **{'decoder.' + k: v for k, v in gsd.items()}},
+          'latent_avg': avg, 'opts': {'stylegan_size': gspec.size, 'start_from_latent_avg': True, 'encoder_type': 'Encoder4Editing'}}
+    torch.save(ck, tmp_path / 'e4e.pt')
+    torch.save({'state_dict': csd}, tmp_path / 'resnet.pt')
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(tmp_path / 'resnet.pt'), 'autoencoder_path': str(tmp_path / 'e4e.pt'),
+                        'interpolation_alphas': list(alphas), 'alpha_attenuation': 1.0, 'initial_noise_eps': noise_eps,
+                        'gaussian_blur_input': blur}, f)
+    eot = 2
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=eot, device=DEV))
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(1, 3, 64, 64, generator=gen)
+    z = torch.randn(eot, gspec.n_latent, gspec.style_dim, generator=gen)
+    noise = torch.randn(eot, 3, 64, 64, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    pre = D.apply_gaussian_blur(xr) if blur else xr
+    pre = D.add_gaussian_noise(pre.repeat(eot, 1, 1, 1), noise, noise_eps)
+    logits, _ = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, pre, alphas, z, 64)
+    mean = logits.mean(dim=0, keepdim=True)
+    (gx,) = torch.autograd.grad(mean[0, 0], [xr])
+    model.model.fixed_noise([z.to(DEV)], noise.to(DEV) if noise_eps else None)
+    xd = x.to(DEV).requires_grad_(True)
+    out = model(xd)
+    (g,) = torch.autograd.grad(out[0, 0], [xd])
+    eng = model.model._engine(eot, eot)
+    assert eng.share_encoder == (noise_eps == 0.0)
+    e = (out.detach().cpu() - mean.detach()).abs().max().item()
+    rel = ((g.cpu() - gx).double().norm() / gx.double().norm()).item()
+    print(f'e4e defender, noise_eps {noise_eps}, blur {blur}: logits err {e:.2e}, input-grad relL2 {rel:.2e}')
+    assert e < 1e-3 and rel < 3e-2
