@@ -70,3 +70,18 @@ for plan, tag in ((eng.fwd, 'fwd'), (eng.bwd, 'bwd')):
         print(f'   generator {k:28s} n {n:3d} {t:9.3f} ms')
     top = sorted(zip(ms, plan.names), reverse=True)[:12]
     print('   top ops: ' + ', '.join(f'{n} {t:.2f}' for t, n in top))
+
+if os.environ.get('GA_GRAPHS', '0') == '1':                 # eager plan replay vs HIP graphs, wall clock per attack step
+    def wall(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(n):
+            eng.forward(); eng.backward()
+        e1.record(); e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    wall(1)
+    eager = wall(4)
+    eng.enable_graphs()
+    wall(1)
+    graph = wall(4)
+    print(json.dumps({'step_ms_eager': eager, 'step_ms_graphs': graph}), flush=True)
