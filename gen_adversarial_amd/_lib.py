@@ -140,7 +140,8 @@ class UnaryDesc(C.Structure):
 
 class ModoutDesc(C.Structure):
     _fields_ = [('t', fp), ('scale', fp), ('add', fp), ('out', fp), ('dout', fp), ('dt', fp),
-                ('N', i32), ('P', i32), ('C', i32), ('act', i32), ('backward', i32), ('W', i32), ('dt_planes', fp * 4)]
+                ('N', i32), ('P', i32), ('C', i32), ('act', i32), ('backward', i32), ('W', i32), ('dt_planes', fp * 4),
+                ('red', fp), ('ws', fp), ('ws_floats', C.c_long)]
 
 
 class Up2BlurDesc(C.Structure):

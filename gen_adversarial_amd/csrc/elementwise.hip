@@ -659,6 +659,50 @@ __global__ void __launch_bounds__(256) pool_denorm_kernel(const ga_pool_denorm_d
     }
 }
 
+// backward of the tail with the demodulation-gradient reduction fused in: block = (row, 64-channel chunk, pixel segment),
+// ql channel-quad lanes x 256/ql pixel lanes (the layout of rowchan_reduce_split_kernel); partial sums of dt * t go to
+// ws[(n*S + seg)*C + c], added in segment order by rowchan_reduce_final_kernel
+__global__ void __launch_bounds__(256) modout_bwd_reduce_kernel(const ga_modout_desc d, const int nchunks, const int ql, const int S,
+                                                                const int seg_len) {
+    __shared__ floatx4 part[256];
+    const int tid = threadIdx.x, c4 = tid % ql, pl = tid / ql, PL = 256 / ql;
+    int bi = blockIdx.x;
+    const int seg = bi % S; bi /= S;
+    const int chunk = bi % nchunks, n = bi / nchunks;
+    const int c = chunk * 64 + 4 * c4;
+    floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < d.C) {
+        floatx4 sc = {1.f, 1.f, 1.f, 1.f};
+        if (d.scale) sc = ld4(d.scale + (size_t)n * d.C + c);
+        const int p1 = min(d.P, (seg + 1) * seg_len);
+        const int H2 = d.W > 0 ? (d.P / d.W) >> 1 : 0, W2 = d.W >> 1;
+        for (int p = seg * seg_len + pl; p < p1; p += PL) {
+            const size_t o = ((size_t)n * d.P + p) * d.C + c;
+            const floatx4 t = ld4(d.t + o);
+            floatx4 u = sc * t;
+            if (d.add) u += ld4(d.add + (size_t)p * d.C + c);
+            const floatx4 g = ld4(d.dout + o);
+            floatx4 dt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dt[e] = g[e] * act_bwd(u[e], d.act) * sc[e];
+            *reinterpret_cast<floatx4*>(d.dt + o) = dt;
+            if (d.dt_planes[0]) {
+                const int h = p / d.W, w = p - h * d.W;
+                float* plane = d.dt_planes[(h & 1) * 2 + (w & 1)];
+                *reinterpret_cast<floatx4*>(plane + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * d.C + c) = dt;
+            }
+            acc += dt * t;
+        }
+    }
+    part[tid] = acc;
+    __syncthreads();
+    for (int st = PL >> 1; st > 0; st >>= 1) {
+        if (pl < st) part[tid] += part[tid + st * ql];
+        __syncthreads();
+    }
+    if (pl == 0 && c < d.C) *reinterpret_cast<floatx4*>(d.ws + ((size_t)n * S + seg) * d.C + c) = part[tid];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // nn.PReLU as its own pass (forward / backward)
 // ---------------------------------------------------------------------------------------------------------------
@@ -1110,6 +1154,27 @@ extern "C" int ga_modout(const ga_modout_desc* d, void* s) {
     if (d->backward && d->dt_planes[0]) {
         if (!d->dt_planes[1] || !d->dt_planes[2] || !d->dt_planes[3]) return GA_E_BADARG;
         if (d->W <= 0 || d->W % 2 || d->P % d->W || (d->P / d->W) % 2) return GA_E_BADARG;
+    }
+    if (d->backward && d->red) {
+        if (!d->ws || d->ws_floats < (long)d->N * d->C) return GA_E_BADARG;
+        if (!aligned16(d->ws) || !aligned16(d->t) || !aligned16(d->dout) || !aligned16(d->dt)) return GA_E_ALIGN;
+        const int nchunks = (d->C + 63) / 64;
+        long S = d->ws_floats / ((long)d->N * d->C);
+        const long want = (2048 + (long)d->N * nchunks - 1) / ((long)d->N * nchunks);     // ~8 workgroups per CU
+        if (S > want) S = want;
+        if (S > (d->P + 255) / 256) S = (d->P + 255) / 256;                               // >= 256 pixels per segment
+        if (S < 1) S = 1;
+        const int q = d->C >= 64 ? 16 : d->C / 4;
+        int ql = 1;
+        while (ql < q) ql <<= 1;
+        const int seg_len = (int)((d->P + S - 1) / S);
+        hipLaunchKernelGGL(modout_bwd_reduce_kernel, dim3((unsigned)(d->N * nchunks * S)), dim3(256), 0, (hipStream_t)s, *d, nchunks, ql,
+                           (int)S, seg_len);
+        ga_rowchan_reduce_desc r = {};
+        r.out = d->red; r.N = d->N; r.P = d->P; r.C = d->C; r.scale = 1.0f; r.ws = d->ws; r.ws_floats = d->ws_floats;
+        const long total = (long)d->N * d->C;
+        hipLaunchKernelGGL(rowchan_reduce_final_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, r, (int)S);
+        return check_launch();
     }
     const long total4 = (long)d->N * d->P * (d->C / 4);
     hipLaunchKernelGGL(modout_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);

@@ -11,8 +11,8 @@ the OUTPUT channels in the tail pass (folding.fold_styled_conv).  Forward / back
   demod  = rsqrt(W2 s^2 + 1e-8)                 ga_unary(square), ga_conv2d 1x1, ga_unary(rsqrt)
   out    = act(demod * t + add)                 ga_modout
   ---- backward (dout given)
-  dt     = dout * act'(u) * demod               ga_modout (u recomputed)
-  d(W2 s^2) = -1/2 demod^2 sum_p dt t           ga_rowchan_reduce, ga_unary
+  dt     = dout * act'(u) * demod               ga_modout (u recomputed; sum_p dt t reduced in the same pass)
+  d(W2 s^2) = -1/2 demod^2 sum_p dt t           ga_unary
   ds     = 2 s W2^T d(W2 s^2) + sum_p dxm x     ga_conv2d 1x1, ga_unary, ga_rowchan_reduce, ga_axpby
   dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d, ga_se_apply (row scale, accumulating into x.g)
   dw_latent += modulation^T ds                  ga_conv2d 1x1
@@ -116,6 +116,11 @@ class StyleGanBuilder:
                 b.W = spec.res
                 for i, pl in enumerate(planes):
                     b.dt_planes[i] = _ptr(pl)
+            gq = None
+            if spec.demodulate:                                  # sum_p dt * t rides on the tail's adjoint (no second read of dt, t)
+                gq = self.scratch((R, 1, 1, co), 'sg.gq')
+                ws = self.scratch((256 * R * co,), 'sg.tail_ws')
+                b.red, b.ws, b.ws_floats = _ptr(gq), _ptr(ws), ws.numel()
             self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
             dxm = self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
@@ -127,9 +132,7 @@ class StyleGanBuilder:
                 self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
             self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, Pin, spec.cin)
             if spec.demodulate:
-                gq = self.scratch((R, 1, 1, co), 'sg.gq')
                 ds2 = self.scratch((R, 1, 1, spec.cin), 'sg.ds2')
-                self._reduce(f'{p}.ddemod', t.g, t.t, gq, R, P, co)
                 self._unary(self.bwd, f'{p}.demod^T', 3, demod, gq, gq)
                 self.conv(self.bwd, f'{p}.demod_sum^T', gq, wts['w2_bwd'], ds2, K=1)
                 self._unary(self.bwd, f'{p}.style^2^T', 1, s.t, ds2, ds2)

@@ -252,6 +252,9 @@ typedef struct ga_modout_desc {
     int W;                    /* row width of the P = H*W pixels; only read when dt_planes is used */
     float* dt_planes[4];      /* backward, optional: dt is ALSO written de-interleaved, pixel (h, w) -> plane (h&1)*2 + (w&1) at
                                  [n, h/2, w/2, C] — the operands of the up-sampling layer's four parity backward convs */
+    float* red;               /* backward, optional: red[n, c] = sum_p dt[n,p,c] * t[n,p,c] (the demodulation gradient's reduction,
+                                 fused into this pass; deterministic two-stage sum through ws, ws_floats >= N*C) */
+    float* ws; long ws_floats;
 } ga_modout_desc;
 int ga_modout(const ga_modout_desc* d, void* stream);
 

@@ -181,7 +181,9 @@ def test_fullsize_e4e_defender_properties():
         torch.cuda.empty_cache()
     l0, p0, _, _ = out[False]
     l1, p1, _, _ = out[True]
-    assert (l0 - l1).abs().max().item() < 1e-4 * max(1.0, l0.abs().max().item()) and (p0 - p1).abs().max().item() < 1e-4
+    # the two plans run the encoder at different row counts (other tiles / split-K orders): rounding-level differences in the
+    # latents pass through 150 random-weight layers, hence the image tolerance of the path (1e-3), not bitwise equality
+    assert (l0 - l1).abs().max().item() < 1e-4 * max(1.0, l0.abs().max().item()) and (p0 - p1).abs().max().item() < 1e-3
 
 
 @pytest.mark.parametrize('noise_eps,blur', [(4.0, False), (0.0, True)])
