@@ -111,7 +111,8 @@ class RepSumDesc(C.Structure):
 
 class Interleave2Desc(C.Structure):
     _fields_ = [('s', fp * 4), ('y', fp), ('dact_x', fp), ('dact_scale', fp), ('dact_shift', fp), ('addend', fp),
-                ('addend2', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dact_act', i32), ('dact_prelu', i32)]
+                ('addend2', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dact_act', i32), ('dact_prelu', i32),
+                ('lds', i32), ('_reserved', i32)]
 
 
 class Maxpool3s2Desc(C.Structure):
@@ -141,7 +142,7 @@ class UnaryDesc(C.Structure):
 class ModoutDesc(C.Structure):
     _fields_ = [('t', fp), ('scale', fp), ('add', fp), ('out', fp), ('dout', fp), ('dt', fp),
                 ('N', i32), ('P', i32), ('C', i32), ('act', i32), ('backward', i32), ('W', i32), ('dt_planes', fp * 4),
-                ('red', fp), ('ws', fp), ('ws_floats', C.c_long)]
+                ('ld_planes', i32), ('_reserved2', i32), ('red', fp), ('ws', fp), ('ws_floats', C.c_long)]
 
 
 class Up2BlurDesc(C.Structure):

@@ -542,7 +542,7 @@ __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, con
             if (d.dt_planes[0]) {
                 const int h = p / d.W, w = p - h * d.W, H2 = (d.P / d.W) >> 1, W2 = d.W >> 1;
                 float* pl = d.dt_planes[(h & 1) * 2 + (w & 1)];
-                *reinterpret_cast<floatx4*>(pl + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * d.C + 4 * q) = o;
+                *reinterpret_cast<floatx4*>(pl + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * (d.ld_planes > 0 ? d.ld_planes : d.C) + 4 * q) = o;
             }
         }
     }
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(256) modout_bwd_reduce_kernel(const ga_modout_
             if (d.dt_planes[0]) {
                 const int h = p / d.W, w = p - h * d.W;
                 float* plane = d.dt_planes[(h & 1) * 2 + (w & 1)];
-                *reinterpret_cast<floatx4*>(plane + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * d.C + c) = dt;
+                *reinterpret_cast<floatx4*>(plane + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * (d.ld_planes > 0 ? d.ld_planes : d.C) + c) = dt;
             }
             acc += dt * t;
         }
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const ga_interleave2_d
         const int h = (int)(r % d.H); const long n = r / d.H;
         const float* src = d.s[h & 1][w & 1];
         floatx4 v = {0.f, 0.f, 0.f, 0.f};
-        if (src) v = *reinterpret_cast<const floatx4*>(src + (((size_t)n * Hh + (h >> 1)) * Wh + (w >> 1)) * d.C + 4 * q);
+        if (src) v = *reinterpret_cast<const floatx4*>(src + (((size_t)n * Hh + (h >> 1)) * Wh + (w >> 1)) * (d.lds > 0 ? d.lds : d.C) + 4 * q);
         const size_t o = (size_t)p * d.C + 4 * q;
         if (d.dact_x) {
             floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);

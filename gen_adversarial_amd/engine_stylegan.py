@@ -16,9 +16,9 @@ the OUTPUT channels in the tail pass (folding.fold_styled_conv).  Forward / back
   ds     = 2 s W2^T d(W2 s^2) + sum_p dxm x     ga_conv2d 1x1, ga_unary, ga_rowchan_reduce, ga_axpby
   dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d, ga_se_apply (row scale, accumulating into x.g)
   dw_latent += modulation^T ds                  ga_conv2d 1x1
-Up-sampling layer: transposed conv + blur = one 6x6 / stride-2 transposed conv (folding.upsample_conv_weights): four 3x3
-parity convs + ga_interleave2 forward; backward the four parity adjoints over the de-interleaved cotangent (written by
-ga_modout beside the interleaved one).  ToRGB skip: ga_up2_blur.
+Up-sampling layer: transposed conv + blur = one 6x6 / stride-2 transposed conv (folding.upsample_conv_weights) = four 3x3
+parity convs, run as ONE 3x3 conv Cin -> 4*Cout into the depth-to-space form + ga_interleave2 forward; backward one 3x3
+conv 4*Cout -> Cin over the cotangent in depth-to-space form (written by ga_modout beside the interleaved one).  ToRGB skip: ga_up2_blur.
 """
 from __future__ import annotations
 
@@ -59,6 +59,9 @@ class StyleGanBuilder:
             if spec.upsample:
                 f.update(F.upsample_conv_weights(f.pop('w64')))
                 f.pop('w'), f.pop('w_bwd'), f.pop('up_bwd')
+                for a_ in (0, 1):
+                    for b_ in (0, 1):
+                        f.pop(f'up{a_}{b_}'), f.pop(f'up_bwd{a_}{b_}')
             f.pop('w64', None)
             return f
         wts = self.devd(f'sg.{p}.{spec.res}.{nkey}', fold)
@@ -70,14 +73,13 @@ class StyleGanBuilder:
         zeros = self.devd(f'sg.zeros.{R}.{spec.cin}', lambda: {'z': torch.zeros(R, spec.cin)})['z']
         pro = dict(pro_scale=s.t, pro_shift=zeros, pro_per_row=1)
         t = Act(self, R, spec.res, spec.res, co, f'{p}.t')
-        if spec.upsample:                                        # four parity convs over the low-resolution input
+        if spec.upsample:                # all four parities as one 3x3 conv Cin -> 4*Cout over the low-resolution input
+            s2d = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d')
+            self.conv(self.fwd, f'{p}.conv[parities]', x.t, wts['up_all'], s2d, K=3, pad=1, **pro)
             il = L.Interleave2Desc()
-            for a in (0, 1):
-                for b in (0, 1):
-                    plane = self.scratch((R, rin, rin, co), f'sg.up{a}{b}')
-                    self.conv(self.fwd, f'{p}.conv[{a}{b}]', x.t, wts[f'up{a}{b}'], plane, K=3, pad=1, **pro)
-                    il.s[2 * a + b] = _ptr(plane)
-            il.y, il.N, il.H, il.W, il.C = _ptr(t.t), R, spec.res, spec.res, co
+            for i in range(4):
+                il.s[i] = _ptr(s2d) + 4 * i * co                 # channel block i of the depth-to-space tensor
+            il.y, il.N, il.H, il.W, il.C, il.lds = _ptr(t.t), R, spec.res, spec.res, co, 4 * co
             self.fwd.add(il, f'{p}.conv.interleave')
         else:
             self.conv(self.fwd, f'{p}.conv', x.t, wts['w'], t.t, K=k, pad=k // 2, **pro)
@@ -110,12 +112,12 @@ class StyleGanBuilder:
             b = L.ModoutDesc()
             b.t, b.scale, b.add, b.dout, b.dt = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.g), _ptr(t.g)
             b.N, b.P, b.C, b.act, b.backward = R, P, co, act, 1
-            planes = []
-            if spec.upsample:                                    # dt also de-interleaved: operands of the parity adjoints
-                planes = [self.scratch((R, rin, rin, co), f'sg.up{a}{c}') for a in (0, 1) for c in (0, 1)]
-                b.W = spec.res
-                for i, pl in enumerate(planes):
-                    b.dt_planes[i] = _ptr(pl)
+            s2d_g = None
+            if spec.upsample:                                    # dt also in depth-to-space form: the operand of the parity adjoint
+                s2d_g = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d')
+                b.W, b.ld_planes = spec.res, 4 * co
+                for i in range(4):
+                    b.dt_planes[i] = _ptr(s2d_g) + 4 * i * co
             gq = None
             if spec.demodulate:                                  # sum_p dt * t rides on the tail's adjoint (no second read of dt, t)
                 gq = self.scratch((R, 1, 1, co), 'sg.gq')
@@ -124,10 +126,8 @@ class StyleGanBuilder:
             self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
             dxm = self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
-            if spec.upsample:                                    # adjoint of (transposed conv + blur): sum of the parity adjoints
-                for i, pl in enumerate(planes):
-                    self.conv(self.bwd, f'{p}.conv^T[{i >> 1}{i & 1}]', pl, wts[f'up_bwd{i >> 1}{i & 1}'], dxm, K=3, pad=1,
-                              addend=(dxm if i else None))
+            if spec.upsample:                                    # adjoint of (transposed conv + blur): one 3x3 conv 4*Cout -> Cin
+                self.conv(self.bwd, f'{p}.conv^T[parities]', s2d_g, wts['up_all_bwd'], dxm, K=3, pad=1)
             else:
                 self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
             self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, Pin, spec.cin)

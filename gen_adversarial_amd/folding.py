@@ -428,6 +428,10 @@ def upsample_conv_weights(w: torch.Tensor) -> dict:
             out[f'up{a}{b}'] = f32(conv_fwd_layout(wp))
             out[f'up_bwd{a}{b}'] = f32(conv_bwd_layout(wp))        # adjoint of the parity conv: over the de-interleaved cotangent
     out['up_bwd'] = f32(conv_fwd_layout(G.permute(1, 0, 2, 3)))
+    # all four parities as ONE 3x3 conv Cin -> 4*Cout (output channel block 2a+b = parity (a, b): the depth-to-space form of the
+    # up-sampled map) and its adjoint 4*Cout -> Cin: the input window is gathered / split once for all parities
+    wall = torch.cat([out[f'up{a}{b}'].double().view(co, 3, 3, ci).permute(0, 3, 1, 2) for a in (0, 1) for b in (0, 1)], dim=0)
+    out['up_all'], out['up_all_bwd'] = f32(conv_fwd_layout(wall)), f32(conv_bwd_layout(wall))
     return out
 
 

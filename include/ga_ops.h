@@ -252,6 +252,8 @@ typedef struct ga_modout_desc {
     int W;                    /* row width of the P = H*W pixels; only read when dt_planes is used */
     float* dt_planes[4];      /* backward, optional: dt is ALSO written de-interleaved, pixel (h, w) -> plane (h&1)*2 + (w&1) at
                                  [n, h/2, w/2, C] — the operands of the up-sampling layer's four parity backward convs */
+    int ld_planes;            /* channel pitch of dt_planes (0 = C) */
+    int _reserved2;
     float* red;               /* backward, optional: red[n, c] = sum_p dt[n,p,c] * t[n,p,c] (the demodulation gradient's reduction,
                                  fused into this pass; deterministic two-stage sum through ws, ws_floats >= N*C) */
     float* ws; long ws_floats;
@@ -366,6 +368,9 @@ typedef struct ga_interleave2_desc {
     int N, H, W, C;           /* output size; H, W even, C % 4 == 0 */
     int dact_act;             /* ga_act */
     int dact_prelu;           /* 1: act' = dact_x > 0 ? 1 : dact_scale[c] (nn.PReLU slopes in dact_scale, dact_shift ignored) */
+    int lds;                  /* channel pitch of the source planes (0 = C): the four planes may be channel slices of ONE
+                                 [N, H/2, W/2, 4C] tensor (StyleGAN2 up-sampling conv: one GEMM for all parities) */
+    int _reserved;
 } ga_interleave2_desc;
 int ga_interleave2(const ga_interleave2_desc* d, void* stream);
 
