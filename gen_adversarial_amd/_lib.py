@@ -161,7 +161,7 @@ class LatentMixDesc(C.Structure):
 
 class PoolDenormDesc(C.Structure):
     _fields_ = [('x', fp), ('y', fp), ('dy', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('k', i32), ('ld', i32),
-                ('backward', i32)]
+                ('backward', i32), ('dy_nchw', fp)]
 
 
 class _OpUnion(C.Union):

@@ -652,7 +652,12 @@ __global__ void __launch_bounds__(256) pool_denorm_kernel(const ga_pool_denorm_d
             const int Y = (int)(r % (d.H * k)); const long n = r / (d.H * k);
             const int h = Y / k, w = X / k;
             const float* g = d.dy + ((((size_t)n * (d.H >> 1) + (h >> 1)) * (d.W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * d.ld;
-            floatx4 v = ld4(g) * inv;
+            floatx4 v = ld4(g);
+            if (d.dy_nchw) {                 // cotangent on the RETURNED purified image [N,3,H,W], added to the classifier's
+                const size_t hw = (size_t)d.H * d.W, o = (size_t)n * 3 * hw + (size_t)h * d.W + w;
+                v[0] += d.dy_nchw[o]; v[1] += d.dy_nchw[o + hw]; v[2] += d.dy_nchw[o + 2 * hw];
+            }
+            v *= inv;
             v[3] = 0.f;
             *reinterpret_cast<floatx4*>(d.dx + i * 4) = v;
         }

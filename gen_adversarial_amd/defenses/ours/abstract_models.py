@@ -40,7 +40,6 @@ class _EngineFn(torch.autograd.Function):
         if want_purified and eng.purified is not None:
             return logits, eng.purified.clone()
         if want_purified and getattr(eng, 'purified_s2d', None) is not None:     # e4e defender: classifier-layout image
-            ctx.mark_non_differentiable_purified = True
             return logits, eng.purified_nchw()
         return logits, x.new_zeros(())
 
@@ -54,10 +53,6 @@ class _EngineFn(torch.autograd.Function):
             eng.forward()
             eng.version += 1
             ctx.version = eng.version
-        if (dpurified is not None and dpurified.dim() == 4 and eng.dpurified is None and
-                getattr(ctx, 'mark_non_differentiable_purified', False) and bool((dpurified != 0).any())):
-            raise NotImplementedError('gradient through the returned purified image is built for the NVAE defender only; '
-                                      'differentiate the logits')
         use_purified = dpurified is not None and dpurified.dim() == 4 and eng.dpurified is not None
         use_logits = dlogits is not None
         if use_logits:

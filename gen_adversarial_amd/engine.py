@@ -497,7 +497,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             else:
                 self.bwd.run(self.stream())
         else:
-            if not self.has_nvae:
+            if self._purified_grad_nhwc is None:
                 raise RuntimeError('classifier-only engine: backward starts from the logits')
             self._purified_grad_nhwc.g.zero_()
             self.bwd.run(self.stream(), start=self.bwd_split)

@@ -235,18 +235,24 @@ class StyleGanBuilder:
         pd.x, pd.y, pd.N, pd.H, pd.W, pd.k, pd.ld, pd.backward = _ptr(img.t), _ptr(pooled.t), R, pool_to, pool_to, k, IMG_LD, 0
         self.fwd.add(pd, 'face_pool_denorm')
 
+        self.purified = None                                     # API output comes from purified_nchw()
+        self.dpurified = self.alloc((R, 3, pool_to, pool_to)) if self.need_backward else None   # cotangent on the returned image
+
         def bwd_pool():
             b = L.PoolDenormDesc()
             b.dy, b.dx, b.N, b.H, b.W, b.k, b.ld, b.backward = _ptr(pooled.g), _ptr(img.g), R, pool_to, pool_to, k, IMG_LD, 1
+            b.dy_nchw = _ptr(self.dpurified)
             self.bwd.add(b, 'face_pool_denorm^T')
             img.g_written = True
         self._bwd_steps.append(bwd_pool)
 
         self.vspec, self.image_s2d = cspec, True
-        self.logits = self._build_resnet(csd, pooled)
+        n_purifier_steps = len(self._bwd_steps)                  # backward steps up to face_pool: replayed alone by
+        self.logits = self._build_resnet(csd, pooled)            # backward(from_logits=False) (gradient from the purified image)
         self.image_s2d = False                                   # x0 (the defender's input) is a plain NHWC image
         self.purified_s2d = pooled
-        self._finish(0)
+        self._purified_grad_nhwc = pooled
+        self._finish(n_purifier_steps)
         return self
 
     def purified_nchw(self) -> torch.Tensor:

@@ -287,9 +287,12 @@ int ga_latent_mix(const ga_latent_mix_desc* d, void* stream);
 /* pSp.face_pool + de-normalisation + hand-over to the classifier (psp.py:26,117; abstract_models.py:184-185): k x k average
  * pooling of the generated image [N, k*H, k*W, 4] (lanes 0..2 = RGB in [-1, 1]) and y = 0.5 * mean + 0.5, written as the
  * space-to-depth image [N, H/2, W/2, 4, ld] the ResNet stem reads (pixel (h, w) -> phase (h&1)*2 + (w&1); lanes >= 3 zero).
- *   backward: dx[n, k*h + a, k*w + b, c] = 0.5 / k^2 * dy[n, h, w, c]  (c < 3; lane 3 zero).   H, W even; ld % 4 == 0. */
+ *   backward: dx[n, k*h + a, k*w + b, c] = 0.5 / k^2 * (dy[n, h, w, c] + dy_nchw[n, c, h, w])  (c < 3; lane 3 zero).
+ *   H, W even; ld % 4 == 0. */
 typedef struct ga_pool_denorm_desc {
     const float* x; float* y; const float* dy; float* dx; int N, H, W, k, ld; int backward;
+    const float* dy_nchw;     /* backward, optional: a second cotangent on the pooled image as the API returns it, [N,3,H,W]
+                                 (MLVGMDefenseModel.__call__(preds_only=False), abstract_models.py:190-193), added to dy */
 } ga_pool_denorm_desc;
 int ga_pool_denorm(const ga_pool_denorm_desc* d, void* stream);
 

@@ -21,6 +21,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from oracle import kinks as K     # relu / leaky_relu / prelu / clamp / max_pool2d: the torch functions unless a test flips near-ties
+
 from gen_adversarial_amd.vgg_spec import VggSpec
 from gen_adversarial_amd.nvae_spec import NVAESpec
 from oracle.nvae_oracle import nvae_purify
@@ -32,20 +34,20 @@ def vgg_forward(sd: SD, spec: VggSpec, x: torch.Tensor) -> torch.Tensor:
     """Vgg.forward — src/classifier/model.py:47-49 (torchvision VGG.forward: features, avgpool(7,7), flatten, classifier)."""
     for op in spec.program:
         if op[0] == 'pool':
-            x = F.max_pool2d(x, 2, 2)
+            x = K.max_pool2d(x, 2, 2)
         else:
             _, i, _, _ = op
             x = F.conv2d(x, sd[f'model.features.{i}.weight'], sd[f'model.features.{i}.bias'], padding=1)
             b = f'model.features.{i + 1}'
             x = F.batch_norm(x, sd[f'{b}.running_mean'], sd[f'{b}.running_var'], sd[f'{b}.weight'], sd[f'{b}.bias'],
                              False, 0.0, 1e-5)
-            x = F.relu(x)
+            x = K.relu(x)
     x = F.adaptive_avg_pool2d(x, (7, 7)).flatten(1)
     x = F.linear(x, sd['model.classifier.0.weight'])
     c = 'model.classifier.1'
     x = F.batch_norm(x, sd[f'{c}.running_mean'], sd[f'{c}.running_var'], sd[f'{c}.weight'], sd[f'{c}.bias'],
                      False, 0.0, 1e-5)
-    x = F.relu(x)
+    x = K.relu(x)
     return F.linear(x, sd['model.classifier.3.weight'], sd['model.classifier.3.bias'])
 
 
@@ -55,18 +57,18 @@ def resnet_forward(sd: SD, spec, x: torch.Tensor) -> torch.Tensor:
     def bn(p, t):
         return F.batch_norm(t, sd[f'{p}.running_mean'], sd[f'{p}.running_var'], sd[f'{p}.weight'], sd[f'{p}.bias'],
                             False, 0.0, 1e-5)
-    x = F.relu(bn('model.bn1', F.conv2d(x, sd['model.conv1.weight'], stride=2, padding=3)))
-    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    x = K.relu(bn('model.bn1', F.conv2d(x, sd['model.conv1.weight'], stride=2, padding=3)))
+    x = K.max_pool2d(x, 3, 2, 1)
     for b in spec.blocks:
         p = b.prefix
-        o = F.relu(bn(f'{p}.bn1', F.conv2d(x, sd[f'{p}.conv1.weight'])))
-        o = F.relu(bn(f'{p}.bn2', F.conv2d(o, sd[f'{p}.conv2.weight'], stride=b.stride, padding=1, groups=b.groups)))
+        o = K.relu(bn(f'{p}.bn1', F.conv2d(x, sd[f'{p}.conv1.weight'])))
+        o = K.relu(bn(f'{p}.bn2', F.conv2d(o, sd[f'{p}.conv2.weight'], stride=b.stride, padding=1, groups=b.groups)))
         o = bn(f'{p}.bn3', F.conv2d(o, sd[f'{p}.conv3.weight']))
         idt = bn(f'{p}.downsample.1', F.conv2d(x, sd[f'{p}.downsample.0.weight'], stride=b.stride)) if b.downsample else x
-        x = F.relu(o + idt)
+        x = K.relu(o + idt)
     x = torch.flatten(F.adaptive_avg_pool2d(x, (1, 1)), 1)
     x = F.linear(x, sd['model.fc.0.weight'])
-    x = F.relu(F.batch_norm(x, sd['model.fc.1.running_mean'], sd['model.fc.1.running_var'], sd['model.fc.1.weight'],
+    x = K.relu(F.batch_norm(x, sd['model.fc.1.running_mean'], sd['model.fc.1.running_var'], sd['model.fc.1.weight'],
                             sd['model.fc.1.bias'], False, 0.0, 1e-5))
     return F.linear(x, sd['model.fc.3.weight'], sd['model.fc.3.bias'])
 
@@ -91,7 +93,7 @@ def add_gaussian_noise(x: torch.Tensor, noise: torch.Tensor, eps: float) -> torc
     """MLVGMDefenseModel.add_gaussian_noise — abstract_models.py:129-143, with the N(0,1) draw passed in."""
     norm = torch.norm(noise.view(noise.size(0), -1), dim=1, keepdim=True)
     scaled = noise * (eps / norm.view(-1, 1, 1, 1))
-    return (x + scaled).clamp(0.0, 1.0)
+    return K.clamp(x + scaled, 0.0, 1.0)
 
 
 def gaussian_kernel1d(k: int, sigma: float = 1.0) -> torch.Tensor:
@@ -140,13 +142,9 @@ def eot_defender(nvae_sd, nvae_spec, vgg_sd, vgg_spec, image: torch.Tensor, eot_
     return torch.mean(logits, dim=0, keepdim=True), purified
 
 
-def e4e_defender_call(esd, espec, gsd, gspec, latent_avg, csd, cspec, x01, alphas, z, pool_to: int):
-    """E4EStyleGanDefenseModel (src/defenses/ours/models.py:80-132) behind MLVGMDefenseModel.__call__ (abstract_models.py:161-193)
-    for a batch already repeated / noised / clamped to [0, 1]:
-      normalize(0.5, 0.5) -> pSp.encode (encoder + latent_avg, psp.py:89-103) -> codes mixed with mapping(z) per latent index
-      (models.py:116-127; z [B, n_latent, D] ~ N(0, 1) supplied by the caller) -> pSp.decode (generator, fixed noise buffers,
-      face_pool; psp.py:112-118) -> denormalize -> classifier.  face_pool = AdaptiveAvgPool2d to pool_to (256 in the reference;
-      a k x k mean when the generator size is a multiple of it).  Returns (logits, purified image in [~0, ~1])."""
+def e4e_purify(esd, espec, gsd, gspec, latent_avg, x01, alphas, z, pool_to: int):
+    """MLVGMDefenseModel.__call__ around E4EStyleGanDefenseModel.purify up to the de-normalised purified image
+    (abstract_models.py:176-185; src/defenses/ours/models.py:105-132; psp.py:89-118): see e4e_defender_call"""
     from oracle.e4e_oracle import e4e_encode
     from oracle import stylegan_oracle as S
     codes = e4e_encode(esd, espec, (x01 - 0.5) / 0.5)
@@ -157,5 +155,16 @@ def e4e_defender_call(esd, espec, gsd, gspec, latent_avg, csd, cspec, x01, alpha
     codes = (1 - a) * codes + a * styles
     img = S.generator_forward(gsd, gspec, codes)
     img = F.adaptive_avg_pool2d(img, (pool_to, pool_to))
-    purified = img * 0.5 + 0.5
+    return img * 0.5 + 0.5
+
+
+def e4e_defender_call(esd, espec, gsd, gspec, latent_avg, csd, cspec, x01, alphas, z, pool_to: int):
+    """E4EStyleGanDefenseModel (src/defenses/ours/models.py:80-132) behind MLVGMDefenseModel.__call__ (abstract_models.py:161-193)
+    for a batch already repeated / noised / clamped to [0, 1]:
+      normalize(0.5, 0.5) -> pSp.encode (encoder + latent_avg, psp.py:89-103) -> codes mixed with mapping(z) per latent index
+      (models.py:116-127; z [B, n_latent, D] ~ N(0, 1) supplied by the caller) -> pSp.decode (generator, fixed noise buffers,
+      face_pool; psp.py:112-118) -> denormalize -> classifier.  face_pool = AdaptiveAvgPool2d to pool_to (256 in the reference;
+      a k x k mean when the generator size is a multiple of it).  Returns (logits, purified image in [~0, ~1]).
+    Pinned by tests/golden/e4e_purify.npz (the reference's own E4EStyleGanDefenseModel, tests/golden/make_stylegan_full_golden.py)."""
+    purified = e4e_purify(esd, espec, gsd, gspec, latent_avg, x01, alphas, z, pool_to)
     return resnet_classifier_call(csd, cspec, purified), purified

@@ -11,6 +11,8 @@ from typing import Dict
 import torch
 import torch.nn.functional as F
 
+from oracle import kinks as K     # relu / leaky_relu / prelu / clamp / max_pool2d: the torch functions unless a test flips near-ties
+
 from gen_adversarial_amd.e4e_spec import E4ESpec
 
 SD = Dict[str, torch.Tensor]
@@ -29,11 +31,11 @@ def ir_se_unit(sd: SD, u, x):
         shortcut = _bn(sd, f'{p}.shortcut_layer.1', F.conv2d(x, sd[f'{p}.shortcut_layer.0.weight'], stride=u.stride))
     r = _bn(sd, f'{p}.res_layer.0', x)
     r = F.conv2d(r, sd[f'{p}.res_layer.1.weight'], padding=1)
-    r = F.prelu(r, sd[f'{p}.res_layer.2.weight'])
+    r = K.prelu(r, sd[f'{p}.res_layer.2.weight'])
     r = F.conv2d(r, sd[f'{p}.res_layer.3.weight'], stride=u.stride, padding=1)
     r = _bn(sd, f'{p}.res_layer.4', r)
     s = F.adaptive_avg_pool2d(r, 1)
-    s = F.relu(F.conv2d(s, sd[f'{p}.res_layer.5.fc1.weight']))
+    s = K.relu(F.conv2d(s, sd[f'{p}.res_layer.5.fc1.weight']))
     s = torch.sigmoid(F.conv2d(s, sd[f'{p}.res_layer.5.fc2.weight']))
     return r * s + shortcut
 
@@ -41,7 +43,7 @@ def ir_se_unit(sd: SD, u, x):
 def style_block(sd: SD, spec: E4ESpec, j: int, x):
     """GradualStyleBlock.forward — encoder.py:33-54; EqualLinear (lr_mul=1) generator.py:69-100."""
     for k in range(spec.style_pools[j]):
-        x = F.leaky_relu(F.conv2d(x, sd[f'styles.{j}.convs.{2 * k}.weight'], sd[f'styles.{j}.convs.{2 * k}.bias'], stride=2, padding=1))
+        x = K.leaky_relu(F.conv2d(x, sd[f'styles.{j}.convs.{2 * k}.weight'], sd[f'styles.{j}.convs.{2 * k}.bias'], stride=2, padding=1))
     x = x.view(-1, spec.style_dim)
     w = sd[f'styles.{j}.linear.weight']
     return F.linear(x, w * (1.0 / math.sqrt(w.shape[1])), sd[f'styles.{j}.linear.bias'])
@@ -54,7 +56,7 @@ def upsample_add(x, y):
 
 def e4e_encode(sd: SD, spec: E4ESpec, x: torch.Tensor) -> torch.Tensor:
     """Encoder4Editing.forward at ProgressiveStage.Inference — encoder.py:108-140.  x: (B,3,H,W) -> (B, style_count, 512)."""
-    x = F.prelu(_bn(sd, 'input_layer.1', F.conv2d(x, sd['input_layer.0.weight'], padding=1)), sd['input_layer.2.weight'])
+    x = K.prelu(_bn(sd, 'input_layer.1', F.conv2d(x, sd['input_layer.0.weight'], padding=1)), sd['input_layer.2.weight'])
     feats = {}
     for i, u in enumerate(spec.units):
         x = ir_se_unit(sd, u, x)

@@ -18,6 +18,8 @@ from typing import Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from oracle import kinks as K     # relu / leaky_relu / prelu / clamp / max_pool2d: the torch functions unless a test flips near-ties
+
 from gen_adversarial_amd.nvae_spec import DecCellSpec, EncCellSpec, NVAESpec, build_spec
 
 SD = Dict[str, torch.Tensor]
@@ -50,7 +52,7 @@ def se(sd: SD, prefix: str, x):
     """SE.forward — architecture.py:52-61."""
     b, c, _, _ = x.shape
     s = torch.mean(x, dim=[2, 3])
-    s = F.relu(F.linear(s, sd[f'{prefix}.linear_1.weight'], sd[f'{prefix}.linear_1.bias']))
+    s = K.relu(F.linear(s, sd[f'{prefix}.linear_1.weight'], sd[f'{prefix}.linear_1.bias']))
     s = torch.sigmoid(F.linear(s, sd[f'{prefix}.linear_2.weight'], sd[f'{prefix}.linear_2.bias']))
     return x * s.view(b, c, 1, 1)
 
@@ -131,9 +133,9 @@ def disc_mix_logistic_mean(logits: torch.Tensor, num_mixtures: int) -> torch.Ten
     probs = torch.softmax(mix, dim=1).unsqueeze(2)
     mu = torch.sum(means * probs, dim=1)                    # B, 3, HW
     k = torch.sum(coeffs * probs, dim=1)
-    r = torch.clamp(mu[:, 0], -1.0, 1.0)
-    g = torch.clamp(mu[:, 1] + k[:, 0] * r, -1.0, 1.0)
-    bl = torch.clamp(mu[:, 2] + k[:, 1] * r + k[:, 2] * g, -1.0, 1.0)
+    r = K.clamp(mu[:, 0], -1.0, 1.0)
+    g = K.clamp(mu[:, 1] + k[:, 0] * r, -1.0, 1.0)
+    bl = K.clamp(mu[:, 2] + k[:, 1] * r + k[:, 2] * g, -1.0, 1.0)
     return torch.stack([r, g, bl], dim=1).reshape(b, 3, h, w)
 
 

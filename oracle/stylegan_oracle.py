@@ -26,6 +26,8 @@ import math
 import torch
 import torch.nn.functional as F
 
+from oracle import kinks as K     # relu / leaky_relu / prelu / clamp / max_pool2d: the torch functions unless a test flips near-ties
+
 
 def equal_linear(x, weight, bias, lr_mul: float = 1.0):
     return F.linear(x, weight * ((1.0 / math.sqrt(weight.shape[1])) * lr_mul), bias * lr_mul)
@@ -73,7 +75,7 @@ def modulated_conv(x, style_latent, weight, mod_weight, mod_bias, demodulate: bo
 
 
 def fused_leaky_relu(x, bias, negative_slope: float = 0.2, scale: float = 2 ** 0.5):
-    return F.leaky_relu(x + bias.view(1, -1, 1, 1), negative_slope) * scale
+    return K.leaky_relu(x + bias.view(1, -1, 1, 1), negative_slope) * scale
 
 
 def styled_conv(sd, p, x, style_latent, noise, upsample: bool = False):
@@ -123,5 +125,5 @@ def mapping_network(sd, z, n_mlp: int = 8, lr_mul: float = 0.01):
     for k in range(1, n_mlp + 1):
         w = sd[f'style.{k}.weight']
         h = F.linear(h, w * ((1.0 / math.sqrt(w.shape[1])) * lr_mul))
-        h = F.leaky_relu(h + sd[f'style.{k}.bias'] * lr_mul, 0.2) * 2 ** 0.5
+        h = K.leaky_relu(h + sd[f'style.{k}.bias'] * lr_mul, 0.2) * 2 ** 0.5
     return h

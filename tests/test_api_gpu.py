@@ -183,7 +183,10 @@ def test_base_classifier_path(setup, tmp_path):
     assert (out.cpu() - ref).abs().max().item() < 2e-4
     (gd,) = torch.autograd.grad(out[:, 7].sum(), [xd])
     diff = (gd.cpu() - gr)
-    assert (diff.norm() / gr.norm()).item() < 2e-2          # max-pool near-ties: see test_engine_gpu
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(clf._engine(3, 1), lambda t: D.classifier_call(vsd, build_vgg_spec(100, 16), t)[:, 7].sum(),
+                                       x, gd, 1e-3, 'classifier input gradient', min_matched=8)
+    assert (diff.norm() / gr.norm()).item() < 2e-2          # secondary (tie-dependent elements included)
     assert clf.get_purified(x) is x
     with pytest.raises(NotImplementedError):
         load(Namespace(config=args.config, experiment='imagenet', defense_type='ours', eot_steps=1, device=DEV))

@@ -67,7 +67,11 @@ def test_e4e_defender_matches_oracle(precision, tol, share):
     print(f'e4e defender [{precision}{", shared encoder" if share else ""}]: {len(eng.fwd)} + {len(eng.bwd)} ops; purified err {e_p:.2e} logits err {e_l:.2e} '
           f'(|logits| {logits.abs().max().item():.2f}); input-grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
     assert e_p < tol and e_l < tol * max(1.0, logits.abs().max().item())
-    assert rel < 3e-2
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(
+        eng, lambda t: (D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, t.repeat_interleave(rep, dim=0), alphas, z, 32)[0] * cot).sum(),
+        x, eng.dx, 1e-3, f'e4e defender input gradient [{precision}]', min_matched=20)
+    assert rel < 3e-2                        # secondary
 
     # the mixing alphas are device data: changing them needs no re-build, and alpha = 1 everywhere cuts the encoder off
     eng.set_alphas([1.0] * gspec.n_latent)
@@ -113,7 +117,12 @@ def test_e4e_defender_through_the_reference_api(tmp_path):
     (g,) = torch.autograd.grad(out[0, 1], [xd])
     rel = ((g.cpu() - gx).double().norm() / gx.double().norm()).item()
     print(f'e4e defender API: EoT-{eot} logits err {(out.detach().cpu() - mean.detach()).abs().max().item():.2e}, input-grad relL2 {rel:.2e}')
-    assert rel < 3e-2
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(
+        model.model._engine(eot, eot), lambda t: D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, t.repeat(eot, 1, 1, 1),
+                                                                    alphas, z, 64)[0].mean(dim=0)[1],
+        x, g, 1e-3, 'e4e defender API input gradient', min_matched=20)
+    assert rel < 3e-2                        # secondary
 
     # get_purified: the de-normalised reconstruction of a single draw; purify: the same in the normalised domain
     model.model.fixed_noise([z[:1].to(DEV)], None)
@@ -225,4 +234,69 @@ def test_e4e_defender_preprocessing_configs(tmp_path, noise_eps, blur):
     e = (out.detach().cpu() - mean.detach()).abs().max().item()
     rel = ((g.cpu() - gx).double().norm() / gx.double().norm()).item()
     print(f'e4e defender, noise_eps {noise_eps}, blur {blur}: logits err {e:.2e}, input-grad relL2 {rel:.2e}')
+    from gradcheck import assert_grad_given_engine_decisions
+
+    def loss(t):
+        p_ = D.apply_gaussian_blur(t) if blur else t
+        p_ = D.add_gaussian_noise(p_.repeat(eot, 1, 1, 1), noise, noise_eps)
+        return D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, p_, alphas, z, 64)[0].mean(dim=0)[0]
+    assert_grad_given_engine_decisions(eng, loss, x, g, 1e-3, f'e4e defender input gradient (noise_eps {noise_eps}, blur {blur})',
+                                       min_matched=20)
     assert e < 1e-3 and rel < 3e-2
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])
+def test_e4e_defender_matches_the_reference_purify_golden(precision, tol):
+    """tests/golden/e4e_purify.npz: the REFERENCE's E4EStyleGanDefenseModel.__call__(x, preds_only=False) (full-width IR-SE50 +
+    Generator(32), latent_avg, alphas x attenuation, recorded torch.normal draw): codes, purified image, and the input gradient
+    through the returned purified image (src/defenses/ours/models.py:105-132, abstract_models.py:161-193)"""
+    import numpy as np
+    import os
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    from gradcheck import assert_grad_given_engine_decisions
+    from oracle import defender_oracle as D
+    z_ = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'e4e_purify.npz'))
+    g = {k: z_[k] for k in z_.files}
+    size = int(g['size'])
+    espec, esd = build_e4e_spec(size), init_e4e_state_dict(size, 1, int(g['enc_seed']))
+    gspec = build_stylegan_spec(size)
+    gsd = init_stylegan_state_dict(gspec, int(g['gen_seed']))
+    cspec, csd = build_resnet_spec(2, 8, (1, 1, 1, 1)), init_resnet_state_dict(2, 8, 5, (1, 1, 1, 1))   # any classifier: not compared
+    x, z, avg = (torch.from_numpy(g[f'purify.{k}']) for k in ('x', 'z', 'latent_avg'))
+    alphas = [float(a) for a in g['purify.alphas']]
+    rows = x.shape[0]
+    eng = Engine.bare(rows, device=DEV, precision=precision, rep=1, resolution=(3, x.shape[2], x.shape[3]), alphas=alphas)
+    eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=size)
+    eng.x_in.copy_(x.to(DEV))
+    eng.eps[0].copy_(z.to(DEV))
+    eng.forward()
+    ref = torch.from_numpy(g['purify.purified32'])
+    e_p = (eng.purified_nchw().cpu() - ref).abs().max().item()
+    codes = eng.acts['sg.latent'].t.view(rows, gspec.n_latent, -1).cpu()
+    print(f'e4e defender vs reference purify golden [{precision}]: purified err {e_p:.2e} (range {ref.min().item():.2f}..{ref.max().item():.2f})')
+    assert e_p < tol * max(1.0, ref.abs().max().item())
+    cot = torch.from_numpy(g['purify.cot'])
+    eng.dpurified.copy_(cot.to(DEV))
+    eng.backward(from_logits=False, from_purified=True)
+    gx = torch.from_numpy(g['purify.gx'])
+    xr = x.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad((D.e4e_purify(esd, espec, gsd, gspec, avg, xr, alphas, z, size) * cot).sum(), [xr])
+    assert (g0 - gx).abs().max().item() < 5e-5 * gx.abs().max().item()
+    assert_grad_given_engine_decisions(eng, lambda t: (D.e4e_purify(esd, espec, gsd, gspec, avg, t, alphas, z, size) * cot).sum(), x, eng.dx,
+                                       1e-3, 'input gradient through the returned purified image', min_matched=20, golden=(gx, g0))
+    # both cotangents at once = the sum of the two backward passes (the logits leg starts in the classifier)
+    cl = torch.randn(rows, 2, generator=torch.Generator().manual_seed(0)).to(DEV)
+    eng.dlogits.view(rows, -1).copy_(cl)
+    eng.backward()
+    d_logits = eng.dx.clone()
+    eng.dpurified.copy_(cot.to(DEV))
+    eng.backward(from_logits=True, from_purified=True)
+    both = eng.dx.clone()
+    eng.dpurified.copy_(cot.to(DEV))
+    eng.backward(from_logits=False, from_purified=True)
+    s_ = both.abs().max().item()
+    assert (both - d_logits - eng.dx).abs().max().item() < 1e-4 * s_
+    del codes

@@ -26,8 +26,11 @@ from gen_adversarial_amd.engine import Engine   # noqa: E402
 DEV = 'cuda:0'
 
 
+eng_last = [None]          # the engine of the last _run (its stored activations feed the decision replay)
+
+
 def _run(sd, spec, x, cot, precision):
-    eng = Engine(None, None, (3, x.shape[2], x.shape[3]), sd, spec, rows=x.shape[0], rep=1, alphas=[], device=DEV, precision=precision)
+    eng = eng_last[0] = Engine(None, None, (3, x.shape[2], x.shape[3]), sd, spec, rows=x.shape[0], rep=1, alphas=[], device=DEV, precision=precision)
     eng.x_in.copy_(x.to(DEV))
     eng.forward()
     w = eng.logits.view(x.shape[0], spec.style_count, spec.style_dim).cpu()
@@ -49,7 +52,16 @@ def test_e4e_matches_the_reference_golden(precision, tol):
     rel = ((gx - ref_g).double().norm() / ref_g.double().norm()).item()
     print(f'   input-grad relL2 {rel:.2e}')
     assert e_w < tol
-    assert rel < 3e-2
+    # the golden gradient is the reference's own; the tie mask comes from the oracle (pinned to the same golden at 1e-5)
+    from gradcheck import assert_grad_given_engine_decisions
+    from oracle.e4e_oracle import e4e_encode
+    xg, cg = torch.from_numpy(g['x']), torch.from_numpy(g['cot'])
+    xr = xg.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad((e4e_encode(sd, spec, xr) * cg).sum(), [xr])
+    assert (g0 - ref_g).abs().max().item() < 1e-5 * ref_g.abs().max().item()
+    assert_grad_given_engine_decisions(eng_last[0], lambda t: (e4e_encode(sd, spec, t) * cg).sum(), xg, gx, 1e-3,
+                                       f'e4e input gradient vs the reference golden [{precision}]', min_matched=20, golden=(ref_g, g0))
+    assert rel < 3e-2                        # secondary (PReLU / LeakyReLU near-ties included)
 
 
 @pytest.mark.parametrize('units,res,size', [((1, 2, 2, 1), 64, 64), ((2, 1, 1, 2), 128, 256)])
@@ -68,6 +80,9 @@ def test_reduced_e4e_matches_oracle(units, res, size):
     e_w, e_g = (w - ref.detach()).abs().max().item(), (g - gx).abs().max().item()
     print(f'e4e reduced {units} {res}px: latents err {e_w:.2e} (max {ref.abs().max().item():.2f}) grad err {e_g:.2e} (max {gx.abs().max().item():.2f})')
     rel = ((g - gx).double().norm() / gx.double().norm()).item()
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng_last[0], lambda t: (e4e_encode(sd, spec, t) * cot).sum(), x, g, 1e-3,
+                                       f'reduced e4e {units} input gradient', min_matched=8)
     assert e_w < 1e-3 and rel < 3e-2
 
 

@@ -173,12 +173,17 @@ def test_against_oracle_on_fresh_inputs(precision, tol, share):
     torch.cuda.synchronize()
     diff = (eng.dx.cpu() - gx).double()
     rel_l2 = (diff.norm() / gx.double().norm()).item()
-    frac_off = (diff.abs() > tol * max(1.0, gx.abs().max().item())).double().mean().item()
     print(f'oracle parity [{precision}]: purified {e_p:.2e} logits {e_l:.2e} nvae-grad {e_gi:.2e} (max {gi_max:.2e}) '
-          f'full-grad relL2 {rel_l2:.2e} frac_off {frac_off:.2e}')
+          f'full-grad relL2 {rel_l2:.2e}')
     assert e_p < tol and e_l < tol
     assert e_gi < tol * max(1.0, gi_max)
-    assert rel_l2 < 2e-2 and frac_off < (5e-3 if precision == 'fp32' else 2e-2)
+    # primary: 1e-3 (of max |g|) on EVERY element given the engine's own ReLU / max-pool decisions (tests/gradcheck.py)
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(
+        eng, lambda t: (D.classifier_call(vsd, vspec, O.nvae_purify(sd, spec, t.repeat_interleave(rep, dim=0).clamp(0, 1),
+                                                                    alphas, eps, 0.6)) * cot).sum(),
+        imgs, eng.dx, 1e-3, f'input gradient through NVAE + VGG [{precision}]', min_matched=8)
+    assert rel_l2 < 2e-2                     # secondary: against the oracle's own decisions (near-tie flips included)
 
 
 def test_blur_and_noise_preprocessing_against_oracle():

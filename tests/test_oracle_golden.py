@@ -159,3 +159,195 @@ def test_stylegan_modulated_conv_oracle_matches_the_reference():
         for got, key in ((y, 'y'), (gx, 'gx'), (gw, 'gw')):
             ref = torch.from_numpy(g[f'{name}.{key}'])
             assert (got.detach() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item()), (name, key)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# StyleGAN2 synthesis network, e4e encoder blocks and the e4e defender against goldens produced by the reference's own
+# Python (tests/golden/make_stylegan_full_golden.py): upfirdn2d_native, the FusedLeakyReLU autograd Functions, StyledConv,
+# ToRGB, Generator(size 32), bottleneck_IR_SE, GradualStyleBlock, E4EStyleGanDefenseModel.__call__ / purify.
+def _close(got, ref, tol=1e-5, what=''):
+    ref = torch.as_tensor(ref)
+    err = (got.detach() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), (what, err, ref.abs().max().item())
+
+
+def test_stylegan_ops_oracle_matches_reference_upfirdn2d_and_fused_lrelu():
+    from oracle import stylegan_oracle as S
+    g = load_golden('stylegan_full.npz')
+    k4 = S.make_kernel() * 4
+    x = torch.from_numpy(g['up.x']).requires_grad_(True)
+    y = S.upfirdn2d(x, k4, up=2, pad=(2, 1))
+    _close(y, g['up.y'], what='upsample')
+    (gx,) = torch.autograd.grad((y * torch.from_numpy(g['up.cot'])).sum(), [x])
+    _close(gx, g['up.gx'], what='upsample grad')
+    _close(S.upfirdn2d(torch.from_numpy(g['blur.x']), k4, pad=(1, 1)), g['blur.y'], what='blur')
+    a = torch.from_numpy(g['lrelu.x']).requires_grad_(True)
+    ya = S.fused_leaky_relu(a, torch.from_numpy(g['lrelu.b']))
+    _close(ya, g['lrelu.y'], what='fused_leaky_relu')
+    (ga,) = torch.autograd.grad((ya * torch.from_numpy(g['lrelu.cot'])).sum(), [a])
+    _close(ga, g['lrelu.gx'], what='fused_leaky_relu grad')      # reference gates on the sign of the saved OUTPUT (.cu case 31)
+
+
+def test_stylegan_layer_oracle_matches_reference_styledconv_and_torgb():
+    from oracle import stylegan_oracle as S
+    from gen_adversarial_amd.stylegan_spec import StyledConvSpec, init_styled_conv_state_dict
+    g = load_golden('stylegan_full.npz')
+    layers = {'styled': StyledConvSpec('conv1', 32, 64, 3, 64, 8, True, True),
+              'styled_up': StyledConvSpec('convs.0', 32, 64, 3, 64, 16, True, True, True),
+              'torgb': StyledConvSpec('to_rgbs.0', 64, 3, 1, 64, 16, False, False)}
+    for name, sp in layers.items():
+        sd = init_styled_conv_state_dict(sp, 41)
+        x = torch.from_numpy(g[f'{name}.x']).requires_grad_(True)
+        w = torch.from_numpy(g[f'{name}.w']).requires_grad_(True)
+        if sp.activate:
+            y = S.styled_conv(sd, sp.prefix, x, w, torch.from_numpy(g[f'{name}.noise']), upsample=sp.upsample)
+            ins = [x, w]
+        else:
+            skip = torch.from_numpy(g[f'{name}.skip']).requires_grad_(True)
+            y = S.to_rgb(sd, sp.prefix, x, w, skip)
+            ins = [x, w, skip]
+        _close(y, g[f'{name}.y'], what=name)
+        grads = torch.autograd.grad((y * torch.from_numpy(g[f'{name}.cot'])).sum(), ins)
+        for got, key in zip(grads, ('gx', 'gw', 'gskip')):
+            _close(got, g[f'{name}.{key}'], what=f'{name}.{key}')
+
+
+def test_stylegan_generator_oracle_matches_reference_generator():
+    """Generator(size=32, 512, 8).forward([latent], input_is_latent=True, randomize_noise=False) and its mapping network"""
+    from oracle import stylegan_oracle as S
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    g = load_golden('stylegan_full.npz')
+    spec = build_stylegan_spec(int(g['gen_size']))
+    sd = init_stylegan_state_dict(spec, int(g['gen_seed']))
+    lat = torch.from_numpy(g['gen.latent']).requires_grad_(True)
+    img = S.generator_forward(sd, spec, lat)
+    _close(img, g['gen.image'], tol=2e-5, what='generator image')
+    (gl,) = torch.autograd.grad((img * torch.from_numpy(g['gen.cot'])).sum(), [lat])
+    _close(gl, g['gen.glatent'], tol=2e-5, what='generator latent gradient')
+    _close(S.mapping_network(sd, torch.from_numpy(g['map.z'])), g['map.styles'], what='mapping network')
+
+
+def test_e4e_block_oracle_matches_reference_ir_se_and_style_block():
+    from types import SimpleNamespace
+    from oracle import e4e_oracle as E
+    g = load_golden('stylegan_full.npz')
+    for name, (cin, depth, stride) in {'irse_same': (16, 16, 2), 'irse_proj': (16, 32, 2), 'irse_s1': (32, 32, 1)}.items():
+        sd = {'u.' + k[len(name) + 4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(name + '.sd.')}
+        x = torch.from_numpy(g[f'{name}.x']).requires_grad_(True)
+        y = E.ir_se_unit(sd, SimpleNamespace(prefix='u', cin=cin, depth=depth, stride=stride), x)
+        _close(y, g[f'{name}.y'], what=name)
+        (gx,) = torch.autograd.grad((y * torch.from_numpy(g[f'{name}.cot'])).sum(), [x])
+        _close(gx, g[f'{name}.gx'], what=name + ' grad')
+    sd = {'styles.0.' + k[len('gsb.sd.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('gsb.sd.')}
+    x = torch.from_numpy(g['gsb.x']).requires_grad_(True)
+    y = E.style_block(sd, SimpleNamespace(style_pools=[3], style_dim=32), 0, x)
+    _close(y, g['gsb.y'], what='GradualStyleBlock')
+    (gx,) = torch.autograd.grad((y * torch.from_numpy(g['gsb.cot'])).sum(), [x])
+    _close(gx, g['gsb.gx'], what='GradualStyleBlock grad')
+
+
+def e4e_purify_case():
+    """the configuration of tests/golden/e4e_purify.npz: full-width IR-SE50 + Generator(32), 64 px inputs"""
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    g = load_golden('e4e_purify.npz')
+    size = int(g['size'])
+    espec, gspec = build_e4e_spec(size), build_stylegan_spec(size)
+    return g, espec, init_e4e_state_dict(size, 1, int(g['enc_seed'])), gspec, init_stylegan_state_dict(gspec, int(g['gen_seed']))
+
+
+class _MeanHead:
+    """the golden's stand-in classifier: logits = per-channel mean of the purified image"""
+
+
+def test_e4e_defender_oracle_matches_reference_purify():
+    """oracle/defender_oracle.e4e_defender_call against E4EStyleGanDefenseModel.__call__(x, preds_only=False) of the reference
+    (normalize -> pSp.encode + latent_avg -> mix with style(z) -> Generator -> face_pool -> denormalize)"""
+    from oracle import defender_oracle as D
+    from oracle.e4e_oracle import e4e_encode
+    g, espec, esd, gspec, gsd = e4e_purify_case()
+    x = torch.from_numpy(g['purify.x']).requires_grad_(True)
+    avg = torch.from_numpy(g['purify.latent_avg'])
+    _close(e4e_encode(esd, espec, (x.detach() - 0.5) / 0.5) + avg, g['purify.codes'], what='pSp.encode')
+    purified = D.e4e_purify(esd, espec, gsd, gspec, avg, x, [float(a) for a in g['purify.alphas']], torch.from_numpy(g['purify.z']), 32)
+    _close(purified, g['purify.purified32'], tol=2e-5, what='purified')
+    _close(purified.mean(dim=(2, 3)), g['purify.preds'], tol=2e-5, what='preds')
+    (gx,) = torch.autograd.grad((purified * torch.from_numpy(g['purify.cot'])).sum(), [x])
+    _close(gx, g['purify.gx'], tol=5e-5, what='input gradient')
+
+
+def test_kink_wrappers_are_the_torch_functions_and_flip_only_near_ties():
+    """oracle/kinks.py: identical to F.* outside `flipped`; inside, forward values unchanged, gradients re-routed only where a
+    decision lies within delta of its tie"""
+    import torch.nn.functional as F
+    from oracle import kinks as K
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 6, 6, generator=g)
+    x[0, 0, 0, 0], x[0, 0, 0, 1] = 1e-6, 0.5               # a ReLU near-tie beside a clear decision
+    w = torch.rand(4, generator=g)
+    for fn, ref in ((K.relu, F.relu), (lambda t: K.leaky_relu(t, 0.2), lambda t: F.leaky_relu(t, 0.2)),
+                    (lambda t: K.prelu(t, w), lambda t: F.prelu(t, w)), (lambda t: K.clamp(t, -1.0, 1.0), lambda t: torch.clamp(t, -1.0, 1.0)),
+                    (lambda t: K.max_pool2d(t, 2, 2), lambda t: F.max_pool2d(t, 2, 2)),
+                    (lambda t: K.max_pool2d(t, 3, 2, 1), lambda t: F.max_pool2d(t, 3, 2, 1))):
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = fn(a), ref(b)
+        assert torch.equal(ya, yb)
+        cot = torch.randn(ya.shape, generator=g)
+        (ga,), (gb,) = torch.autograd.grad((ya * cot).sum(), [a]), torch.autograd.grad((yb * cot).sum(), [b])
+        assert torch.equal(ga, gb)
+        with K.flipped(0.0):                                   # nothing is within 0 of a tie
+            c = x.clone().requires_grad_(True)
+            yc = fn(c)
+            (gc,) = torch.autograd.grad((yc * cot).sum(), [c])
+        assert torch.allclose(yc, yb, atol=0) and torch.allclose(gc, gb, atol=1e-7)
+    with K.flipped(1e-4) as st:
+        c = x.clone().requires_grad_(True)
+        (gc,) = torch.autograd.grad(K.relu(c).sum(), [c])
+    assert st['count'] == 1 and gc[0, 0, 0, 0] == 0.0 and gc[0, 0, 0, 1] == 1.0          # only the near-tie flipped (1 -> 0)
+    p = torch.tensor([[[[1.0, 1.00001], [0.2, -3.0]]]])
+    with K.flipped(1e-4):
+        c = p.clone().requires_grad_(True)
+        (gc,) = torch.autograd.grad(K.max_pool2d(c, 2, 2).sum(), [c])
+    assert gc.flatten().tolist() == [1.0, 0.0, 0.0, 0.0]                                  # routed to the runner-up
+    gn = torch.tensor([1.0, 0.0, 2.0]); gf = torch.tensor([1.0, 0.5, 2.0])
+    assert K.tie_mask(gn, gf, 1e-3).tolist() == [False, True, False]
+
+
+def test_decision_replay_reproduces_another_runs_gradient_exactly():
+    """oracle/kinks.Replay: a VGG fed a nearly flat image (what a random-weight NVAE produces: max-pool and ReLU near-ties
+    everywhere) and the same image perturbed by 5e-7 disagree on a handful of decisions and by percents in the input gradient;
+    replaying run A's decisions (read from its stored pre-activations) in run B reproduces A's gradient bit for bit"""
+    import torch.nn.functional as F
+    from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict
+    from oracle import defender_oracle as D, kinks as K
+    vspec, vsd = build_vgg_spec(100, 4), init_vgg_state_dict(100, 4, 1)
+    g = torch.Generator().manual_seed(0)
+    base = F.avg_pool2d(F.pad(0.456 + 0.044 * torch.randn(2, 3, 64, 64, generator=g), (2, 2, 2, 2), mode='replicate'), 5, 1)
+    cot = torch.randn(2, 100, generator=g)
+
+    def run(x, cands=None):
+        rec, orig = [], F.batch_norm
+
+        def bn(*a, **k):
+            y = orig(*a, **k)
+            rec.append(y.detach().clone())
+            return y
+        F.batch_norm = bn
+        try:
+            p = x.clone().requires_grad_(True)
+            if cands is None:
+                (D.classifier_call(vsd, vspec, p) * cot).sum().backward()
+                rp = None
+            else:
+                with K.replaying(cands) as rp:
+                    (D.classifier_call(vsd, vspec, p) * cot).sum().backward()
+        finally:
+            F.batch_norm = orig
+        return p.grad, [r if r.dim() == 4 else r[:, :, None, None] for r in rec], rp
+    g_a, cand_a, _ = run(base)
+    x_b = base + 5e-7 * torch.randn(base.shape, generator=g)
+    g_b, _, _ = run(x_b)
+    g_r, _, rp = run(x_b, cand_a)
+    assert rp.matched == rp.sites == 14 and rp.flips > 0 and rp.worst_margin < 1e-4
+    assert (g_a - g_b).abs().max() > 1e-3 * g_a.abs().max()            # the two runs really disagree
+    assert torch.equal(g_r, g_a)

@@ -43,7 +43,10 @@ def _check(width_div, blocks, res, rows, precision, tol, groups=1, wpg=64, n_cla
     print(f'resnet wd{width_div} {blocks} g{groups} {res}px [{precision}]: logits err {e_l:.2e} (|logits| {logits.abs().max().item():.2f}) '
           f'grad relL2 {rel:.2e} (|g| {gx.abs().max().item():.2e})')
     assert e_l < tol
-    assert rel < 2e-2            # the stem's max pool and the ReLUs make the gradient discontinuous at near-ties
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda t: (D.resnet_classifier_call(sd, spec, t) * cot).sum(), x, eng.dx, 1e-3,
+                                       f'resnet input gradient [{precision}]', min_matched=8)
+    assert rel < 2e-2            # secondary: the stem's max pool and the ReLUs make the gradient discontinuous at near-ties
 
 
 @pytest.mark.parametrize('precision,tol', [('fp32', 2e-4), ('bf16x3', 1e-3)])

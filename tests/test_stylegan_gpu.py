@@ -200,4 +200,106 @@ def test_generator_matches_oracle(precision, tol):
     got = alat.g.view(rows, spec.n_latent, spec.style_dim).cpu()
     rel = ((got - glat).double().norm() / glat.double().norm()).item()
     print(f'   d/dlatent relL2 {rel:.2e} max err {(got - glat).abs().max().item():.2e} of {glat.abs().max().item():.2e}')
-    assert rel < 5e-3                    # leaky-ReLU kinks of 9 hidden layers (see the chain test)
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda t: (S.generator_forward(sd, spec, t) * cot).sum(), lat, got, 1e-3,
+                                       f'generator d/dlatent [{precision}]', min_matched=9)
+    assert rel < 5e-3                    # secondary: leaky-ReLU kinks of 9 hidden layers (see the chain test)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# against goldens produced by the REFERENCE's own StyledConv / ToRGB / Generator (tests/golden/make_stylegan_full_golden.py)
+def _golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'stylegan_full.npz'))
+    return {k: z[k] for k in z.files}
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-3)])
+def test_styled_conv_and_torgb_match_the_reference_golden(precision, tol):
+    """reference StyledConv (plain and up-sampling: transposed conv + upfirdn2d blur + noise + FusedLeakyReLU) and ToRGB with
+    its upfirdn2d-up-sampled skip: output, d/dx, d/dstyle, d/dskip"""
+    from oracle import stylegan_oracle as S
+    from gradcheck import assert_grad_given_engine_decisions
+    g = _golden()
+    layers = {'styled': StyledConvSpec('conv1', 32, 64, 3, 64, 8, True, True),
+              'styled_up': StyledConvSpec('convs.0', 32, 64, 3, 64, 16, True, True, True),
+              'torgb': StyledConvSpec('to_rgbs.0', 64, 3, 1, 64, 16, False, False)}
+    for name, sp in layers.items():
+        sd = init_styled_conv_state_dict(sp, 41)
+        x, w, cot = (torch.from_numpy(g[f'{name}.{k}']) for k in ('x', 'w', 'cot'))
+        rows, rin = x.shape[0], x.shape[2]
+        eng = Engine.bare(rows, device=DEV, precision=precision)
+        ax, aw = Act(eng, rows, rin, rin, sp.cin, 'x'), Act(eng, rows, 1, 1, sp.style_dim, 'w')
+        skip = None
+        if sp.activate:
+            out = eng.styled_conv(sd, sp, ax, aw, noise=torch.from_numpy(g[f'{name}.noise'])[0, 0])
+        else:
+            skip = Act(eng, rows, sp.res // 2, sp.res // 2, 4, 'skip')
+            out = eng.styled_conv(sd, sp, ax, aw, skip=skip)
+        eng.finish()
+        ax.t.copy_(nhwc(x))
+        aw.t.view(rows, -1).copy_(w.to(DEV))
+        if skip is not None:
+            skip.t.zero_()
+            skip.t[..., :3].copy_(nhwc(torch.from_numpy(g[f'{name}.skip'])))
+        eng.forward()
+        print(f'{name} vs reference golden [{precision}]')
+        close(nchw(out.t, sp.cout), torch.from_numpy(g[f'{name}.y']), tol, 'y')
+        out.g.zero_()
+        out.g[..., :sp.cout].copy_(nhwc(cot))
+        eng.bwd.run(eng.stream())
+        torch.cuda.synchronize()
+        if sp.activate:          # leaky-ReLU kink: tie mask from the oracle (pinned to this golden at 1e-5 on the CPU)
+            noise = torch.from_numpy(g[f'{name}.noise'])
+            for i, (got, key) in enumerate(((nchw(ax.g), 'gx'), (aw.g.view(rows, -1).cpu(), 'gw'))):
+                other = w if i == 0 else x
+                fn = (lambda t: (S.styled_conv(sd, sp.prefix, t, other, noise, upsample=sp.upsample) * cot).sum()) if i == 0 else \
+                     (lambda t: (S.styled_conv(sd, sp.prefix, other, t, noise, upsample=sp.upsample) * cot).sum())
+                arg = x if i == 0 else w
+                ar = arg.clone().requires_grad_(True)
+                (g0,) = torch.autograd.grad(fn(ar), [ar])
+                ref = torch.from_numpy(g[f'{name}.{key}'])
+                assert_grad_given_engine_decisions(eng, fn, arg, got, tol, f'{name}.{key}', golden=(ref, g0))
+        else:
+            close(nchw(ax.g), torch.from_numpy(g[f'{name}.gx']), tol, 'gx')
+            close(aw.g.view(rows, -1).cpu(), torch.from_numpy(g[f'{name}.gw']), tol, 'gw')
+            close(nchw(skip.g, 3), torch.from_numpy(g[f'{name}.gskip']), tol, 'gskip')
+
+
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16x3', 1e-3)])
+def test_generator_and_mapping_match_the_reference_golden(precision, tol):
+    """the reference's Generator(size=32, 512, 8) at full width (512 channels, 8 latents, 3 up-sampling stages):
+    forward([latent], input_is_latent=True, randomize_noise=False) image, d/dlatent, and the mapping network"""
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    from oracle import stylegan_oracle as S
+    from gradcheck import assert_grad_given_engine_decisions
+    g = _golden()
+    spec = build_stylegan_spec(int(g['gen_size']))
+    sd = init_stylegan_state_dict(spec, int(g['gen_seed']))
+    lat, cot = torch.from_numpy(g['gen.latent']), torch.from_numpy(g['gen.cot'])
+    rows = lat.shape[0]
+    eng = Engine.bare(rows, device=DEV, precision=precision)
+    alat = Act(eng, rows, 1, 1, spec.n_latent * spec.style_dim, 'latent')
+    aimg = eng.build_stylegan(sd, spec, alat)
+    eng.finish()
+    alat.t.view(rows, -1).copy_(lat.reshape(rows, -1).to(DEV))
+    eng.forward()
+    print(f'Generator(32) vs reference golden [{precision}]')
+    close(nchw(aimg.t, 3), torch.from_numpy(g['gen.image']), tol, 'image')
+    aimg.g.zero_()
+    aimg.g[..., :3].copy_(nhwc(cot))
+    eng.bwd.run(eng.stream())
+    torch.cuda.synchronize()
+    got = alat.g.view(rows, spec.n_latent, spec.style_dim).cpu()
+    ref = torch.from_numpy(g['gen.glatent'])
+    lr = lat.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad((S.generator_forward(sd, spec, lr) * cot).sum(), [lr])
+    assert_grad_given_engine_decisions(eng, lambda t: (S.generator_forward(sd, spec, t) * cot).sum(), lat, got, 1e-3, 'd/dlatent',
+                                       min_matched=7, golden=(ref, g0))
+    z = torch.from_numpy(g['map.z'])
+    em = Engine.bare(z.shape[0], device=DEV, precision=precision)
+    zb = em.alloc(tuple(z.shape))
+    styles = em.build_mapping(sd, zb)
+    em.finish()
+    zb.copy_(z.to(DEV))
+    em.forward()
+    close(styles.view(z.shape[0], -1).cpu(), torch.from_numpy(g['map.styles']), tol, 'mapping network')
