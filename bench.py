@@ -122,6 +122,10 @@ class AttackStep:
         self.logits[lo:hi] = eng.logits.view(-1, self.rep, eng.logits.shape[-1]).mean(dim=1)
 
     def _run(self, fn):
+        if self.streams[0] is None:                          # stub rehearsal on the CPU: no streams
+            for c in range(self.x_orig.shape[0] // self.per):
+                fn(self.engines[c % len(self.engines)], c * self.per, (c + 1) * self.per)
+            return
         main = torch.cuda.current_stream()
         for s in self.streams:
             s.wait_stream(main)
@@ -193,6 +197,57 @@ def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
 
+class StubEngine:
+    """TEST REHEARSAL ONLY (--stub-engine, gloo): a CPU stand-in with the engine's buffers so that the launcher, the
+    rendezvous, the barrier + max-over-ranks timing, the all-gather and the JSON line can be exercised without a GPU.
+    It computes nothing of the path; the line it produces says so (`data: stub`)."""
+
+    def __init__(self, rows, rep, n_classes=100):
+        self.rows, self.rep, self.noise_eps, self.share_encoder, self.bytes = rows, rep, 0.0, False, 0
+        self.x_in = torch.zeros(rows // rep, 3, 64, 64)
+        self.eps = [torch.zeros(rows, 4)]
+        self.logits = torch.zeros(rows, n_classes)
+        self.dlogits = torch.zeros(rows, n_classes)
+        self.dx = torch.zeros(rows // rep, 3, 64, 64)
+        self.fwd, self.bwd = [], []
+
+    def forward(self):
+        self.logits.copy_(self.x_in.mean(dim=(1, 2, 3)).repeat_interleave(self.rep).unsqueeze(1) * torch.arange(1, self.logits.shape[1] + 1))
+
+    def backward(self):
+        self.dx.fill_(self.dlogits.sum().item())
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh processes, one rank per GPU, as the reference spawns one
+    process per GPU itself (src/experiments/test_defense.py:296-302).  Runs BEFORE anything in this process touches the GPU;
+    the children are ordinary `python bench.py` processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what
+    torch.distributed.run would set).  Rank 0's stdout (the one JSON line) is passed through; any failing rank fails the run."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if args.backend == 'nccl':
+        ndev = torch.cuda.device_count()                    # counting devices does not initialise the GPU
+        if ndev < n:
+            raise SystemExit(f'--gpus {n}: this node has {ndev} GPU(s); one rank per GPU is required '
+                             '(--backend gloo rehearses more ranks than GPUs)')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f'bench.py --gpus {n}: rank exit codes {codes}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -213,19 +268,31 @@ def main():
                     help='collective backend; gloo (CPU tensors) only to rehearse N>1 on a box with fewer GPUs than ranks')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default='bf16x3',
                     help="dense contractions: 'bf16x3' = 3 bf16 MFMAs per product (logits within ~2e-5 of fp32), 'fp32' = exact f32 MFMA")
+    ap.add_argument('--stub-engine', action='store_true',
+                    help='TEST REHEARSAL ONLY: CPU stand-in engines (needs --backend gloo); exercises launcher / collectives / JSON')
     args = ap.parse_args()
+    if args.stub_engine and args.backend != 'gloo':
+        raise SystemExit('--stub-engine is a CPU rehearsal of the multi-rank plumbing: use it with --backend gloo')
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if local_rank < ndev else local_rank % ndev      # rehearsal: several ranks share one GPU
-    if local_rank >= ndev and args.backend == 'nccl':
-        raise SystemExit(f'rank {rank}: no GPU {local_rank} on this node (use --backend gloo only to rehearse)')
-    torch.cuda.set_device(dev_index)
-    device = f'cuda:{dev_index}'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N starts them '
+                         'itself; under torch.distributed.run pass the same N)')
+    if args.stub_engine:
+        device = 'cpu'
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU: the hot path has no CPU fallback')
+        ndev = torch.cuda.device_count()
+        dev_index = local_rank if local_rank < ndev else local_rank % ndev      # rehearsal: several ranks share one GPU
+        if local_rank >= ndev and args.backend == 'nccl':
+            raise SystemExit(f'rank {rank}: no GPU {local_rank} on this node (use --backend gloo only to rehearse)')
+        torch.cuda.set_device(dev_index)
+        device = f'cuda:{dev_index}'
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -242,14 +309,18 @@ def main():
     n_eng = max(1, min(args.streams, n_chunks))
     rows_per_step = args.images * args.eot
     log(f'rank {rank}/{world}: building weights + {n_eng} engine(s) of {args.chunk_rows} rows')
-    eng, model = build_model(device, args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
-    engines = [eng]
-    for _ in range(n_eng - 1):
-        engines.append(clone_engine(eng, model, device, args))
-    streams = [torch.cuda.Stream(device=device) for _ in engines]
+    if args.stub_engine:
+        eng, model = StubEngine(args.chunk_rows, args.eot), None
+        engines, streams = [eng], [None]
+    else:
+        eng, model = build_model(device, args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
+        engines = [eng]
+        for _ in range(n_eng - 1):
+            engines.append(clone_engine(eng, model, device, args))
+        streams = [torch.cuda.Stream(device=device) for _ in engines]
     log(f'engines ready: {sum(e.bytes for e in engines) / 1e9:.1f} GB activations + weights, {len(eng.fwd)} fwd + {len(eng.bwd)} bwd ops per chunk, '
         f'{n_chunks} chunks per step')
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    g = torch.Generator(device=device).manual_seed(1234 + rank)      # every rank its own images (weak scaling)
     x = torch.rand(args.images, 3, 64, 64, device=device, generator=g)
     # labels = clean prediction of the defender, so that the attack starts from "correct" 
     step = AttackStep(engines, streams, None, x)
@@ -261,10 +332,12 @@ def main():
     log('warmup done')
 
     def sync():
-        torch.cuda.synchronize()
+        if not args.stub_engine:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if not args.stub_engine:
+                torch.cuda.synchronize()
 
     sync()
     t0 = time.perf_counter()
@@ -285,7 +358,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
-    if rank == 0:
+    if rank == 0 and args.stub_engine:
+        print(json.dumps({'metric': 'purified images/sec (attack+encode+decode)', 'value': rows_per_step * world * args.steps / dt,
+                          'unit': 'defender rows/s (rows = images x EoT-32)', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                          'dtype': 'none', 'data': 'stub (CPU rehearsal of the multi-rank plumbing; nothing of the path computed)',
+                          'config': {'workload': 'stub', 'parallelism': f'image-sharded x{world}'},
+                          'accuracy_counters': [float(counters[0].item()), float(counters[1].item())]}))
+    elif rank == 0:
         log(f'timed region: {dt:.3f} s for {args.steps} steps')
         rows_total = rows_per_step * world * args.steps
         # ---- roofline of the dominant kernel (conv_mfma_kernel): HIP events on the plan's stream, per launch

@@ -102,7 +102,8 @@ class AxpbyDesc(C.Structure):
 
 
 class BlurDesc(C.Structure):
-    _fields_ = [('x', fp), ('y', fp), ('taps', fp), ('planes', i32), ('H', i32), ('W', i32), ('k', i32), ('backward', i32)]
+    _fields_ = [('x', fp), ('y', fp), ('taps', fp), ('planes', i32), ('H', i32), ('W', i32), ('k', i32), ('backward', i32),
+                ('radius', i32), ('tmp', fp)]
 
 
 class RepSumDesc(C.Structure):
@@ -192,7 +193,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
            'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
-           'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op']
+           'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op', 'ga_debug_set_conv_row_limit']
 
 
 def _load():
@@ -234,6 +235,8 @@ def _load():
     lib.ga_last_hip_error.restype = C.c_char_p
     lib.ga_abi_version.restype = C.c_int
     lib.ga_sizeof_op.restype = C.c_ulong
+    lib.ga_debug_set_conv_row_limit.restype = C.c_long
+    lib.ga_debug_set_conv_row_limit.argtypes = [C.c_long]
     if lib.ga_sizeof_op() != C.sizeof(Op):
         raise ImportError(f'ABI mismatch: library ga_op is {lib.ga_sizeof_op()} bytes, binding is {C.sizeof(Op)}')
     return lib

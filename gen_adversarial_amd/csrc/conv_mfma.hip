@@ -433,6 +433,16 @@ int conv_halo3_supports(const ga_conv_desc& d);
 
 }  // namespace ga
 
+// byte extent of one operand above which ga_conv2d convolves row sub-batches (the fast loaders' 31-bit offsets); lowered by
+// ga_debug_set_conv_row_limit so that tests reach the sub-batch path at small sizes
+static long g_conv_row_limit = 0x7fffff00L;
+static long ga_conv_row_limit() { return g_conv_row_limit; }
+extern "C" long ga_debug_set_conv_row_limit(long bytes) {
+    const long old = g_conv_row_limit;
+    g_conv_row_limit = bytes > 0 ? bytes : 0x7fffff00L;
+    return old;
+}
+
 extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     ga::clear_stale_error();
     using namespace ga;
@@ -454,10 +464,21 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     // at a few dozen rows) is convolved in sub-batches of rows that fit, each an ordinary launch on the same stream.
     {
         const long row_x = (long)d.Hi * d.Wi * d.ldx * 4, row_x2 = d.C2 > 0 ? (long)d.Hi * d.Wi * d.ldx2 * 4 : 0;
-        const long row_max = row_x > row_x2 ? row_x : row_x2;
-        const long lim = 0x7fffff00L;
+        long row_max = row_x > row_x2 ? row_x : row_x2;
+        const long pix_out = (long)d.Ho * d.Wo * 4;          // every per-row operand counts: output, addends, act' source
+        if (pix_out * d.ldy > row_max) row_max = pix_out * d.ldy;
+        if (d.addend && !d.addend_bcast_n && pix_out * d.ldadd > row_max) row_max = pix_out * d.ldadd;
+        if (d.addend2 && pix_out * d.ldadd2 > row_max) row_max = pix_out * d.ldadd2;
+        if (d.dact_x && pix_out * d.lddact > row_max) row_max = pix_out * d.lddact;
+        const long lim = ga_conv_row_limit();
         if (d.N > 1 && row_max * d.N >= lim && row_max < lim) {
-            const int sub = (int)((lim - 1) / row_max);
+            int sub = (int)((lim - 1) / row_max);
+            const int arep = d.addend && !d.addend_bcast_n && d.addend_rep > 1 ? d.addend_rep : 1;
+            if (arep > 1) {                                  // an addend shared by `arep` consecutive rows: cut at its row boundaries
+                if (d.N % arep) return GA_E_BADARG;
+                sub -= sub % arep;
+                if (sub < arep) return GA_E_UNSUPPORTED;
+            }
             for (int n0 = 0; n0 < d.N; n0 += sub) {
                 ga_conv_desc s = d;
                 s.N = d.N - n0 < sub ? d.N - n0 : sub;
@@ -465,7 +486,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
                 s.x = d.x + pin * d.ldx;
                 if (d.x2) s.x2 = d.x2 + pin * d.ldx2;
                 s.y = d.y + pout * d.ldy;
-                if (d.addend && !d.addend_bcast_n) s.addend = d.addend + pout * d.ldadd;
+                if (d.addend && !d.addend_bcast_n) s.addend = d.addend + (size_t)(n0 / arep) * d.Ho * d.Wo * d.ldadd;
                 if (d.addend2) s.addend2 = d.addend2 + pout * d.ldadd2;
                 if (d.dact_x) s.dact_x = d.dact_x + pout * d.lddact;
                 if (d.pro_scale && d.pro_per_row) {

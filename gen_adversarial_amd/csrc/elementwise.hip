@@ -953,15 +953,17 @@ __device__ __forceinline__ int reflect_idx(int t, const int n) {       // 'refle
 }
 
 // forward line filter: out[i] = sum_k g[k] in[reflect(i + k - p)];  adjoint: out[j] = sum over (i,k) with reflect(i+k-p) = j
+// taps q in [p - r, p + r] only (r = the caller's `radius`, or k/2): a sigma-1 Gaussian of 255 taps (256-px images) has 25 taps
+// above 1e-31 of its peak
 __device__ __forceinline__ float blur_tap_sum(const float* line, const int stride, const int n, const int i, const float* g,
-                                              const int k, const bool adjoint) {
+                                              const int k, const bool adjoint, const int r) {
     const int p = k / 2;
     float acc = 0.f;
     if (!adjoint) {
-        for (int q = 0; q < k; ++q) acc += g[q] * line[reflect_idx(i + q - p, n) * stride];
+        for (int q = p - r; q <= p + r; ++q) acc += g[q] * line[reflect_idx(i + q - p, n) * stride];
     } else {
         // sources t that reflect onto j = i: t = j, t = -j (j >= 1), t = 2(n-1) - j (j <= n-2); t = i' + q - p
-        for (int q = 0; q < k; ++q) {
+        for (int q = p - r; q <= p + r; ++q) {
             const int a = i - q + p;
             if (a >= 0 && a < n) acc += g[q] * line[a * stride];
             if (i >= 1) { const int b2 = -i - q + p; if (b2 >= 0 && b2 < n) acc += g[q] * line[b2 * stride]; }
@@ -971,7 +973,8 @@ __device__ __forceinline__ float blur_tap_sum(const float* line, const int strid
     return acc;
 }
 
-__global__ void __launch_bounds__(256) gauss_blur_kernel(const ga_blur_desc d) {
+// whole plane in LDS (planes up to ~90 x 90: the 64-px images of the ids experiment)
+__global__ void __launch_bounds__(256) gauss_blur_kernel(const ga_blur_desc d, const int r) {
     extern __shared__ float bl_s[];
     float* a = bl_s;                       // [H][W]
     float* b = bl_s + d.H * d.W;           // [H][W]
@@ -985,13 +988,47 @@ __global__ void __launch_bounds__(256) gauss_blur_kernel(const ga_blur_desc d) {
     const bool adj = d.backward != 0;
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / d.W, w = i - h * d.W;
-        b[i] = adj ? blur_tap_sum(a + w, d.W, d.H, h, g, d.k, true) : blur_tap_sum(a + h * d.W, 1, d.W, w, g, d.k, false);
+        b[i] = adj ? blur_tap_sum(a + w, d.W, d.H, h, g, d.k, true, r) : blur_tap_sum(a + h * d.W, 1, d.W, w, g, d.k, false, r);
     }
     __syncthreads();
     float* dst = d.y + (size_t)blockIdx.x * HW;
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int h = i / d.W, w = i - h * d.W;
-        dst[i] = adj ? blur_tap_sum(b + h * d.W, 1, d.W, w, g, d.k, true) : blur_tap_sum(b + w, d.W, d.H, h, g, d.k, false);
+        dst[i] = adj ? blur_tap_sum(b + h * d.W, 1, d.W, w, g, d.k, true, r) : blur_tap_sum(b + w, d.W, d.H, h, g, d.k, false, r);
+    }
+}
+
+// one separable pass over larger planes (128 / 256-px images of the cars / gender experiments), through a caller-owned
+// intermediate plane set: along x a workgroup stages RT whole rows, along y a strip of CT columns x all rows (128-B segments of
+// consecutive columns: coalesced); every output reads its 2r + 1 taps from LDS
+__global__ void __launch_bounds__(256) gauss_blur_pass_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ taps,
+                                                              const int H, const int W, const int k, const int r, const int along_y,
+                                                              const int adjoint, const int T, const int tiles) {
+    extern __shared__ float bl_s[];
+    const int plane = blockIdx.x / tiles, tile = blockIdx.x - plane * tiles;
+    const size_t base = (size_t)plane * H * W;
+    float* g = bl_s;                       // [k]
+    float* a = bl_s + ((k + 3) & ~3);
+    for (int i = threadIdx.x; i < k; i += 256) g[i] = taps[i];
+    if (!along_y) {                        // rows tile*T .. +T, each W long
+        const int h0 = tile * T, nr = min(T, H - h0);
+        for (int i = threadIdx.x; i < nr * W; i += 256) a[i] = src[base + (size_t)h0 * W + i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * W; i += 256) {
+            const int hh = i / W, w = i - hh * W;
+            dst[base + (size_t)h0 * W + i] = blur_tap_sum(a + hh * W, 1, W, w, g, k, adjoint != 0, r);
+        }
+    } else {                               // columns tile*T .. +T, each H long, stored [H][T]
+        const int w0 = tile * T, nc = min(T, W - w0);
+        for (int i = threadIdx.x; i < H * T; i += 256) {
+            const int h = i / T, c = i - h * T;
+            if (c < nc) a[i] = src[base + (size_t)h * W + w0 + c];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < H * T; i += 256) {
+            const int h = i / T, c = i - h * T;
+            if (c < nc) dst[base + (size_t)h * W + w0 + c] = blur_tap_sum(a + c, T, H, h, g, k, adjoint != 0, r);
+        }
     }
 }
 
@@ -1290,10 +1327,30 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
 extern "C" int ga_gauss_blur(const ga_blur_desc* d, void* s) {
     ga::clear_stale_error();
     if (!d || !d->x || !d->y || !d->taps || d->planes <= 0 || d->H <= 0 || d->W <= 0 || d->k <= 0) return GA_E_BADARG;
-    if (!(d->k & 1) || d->k / 2 >= d->H || d->k / 2 >= d->W) return GA_E_UNSUPPORTED;
+    if (!(d->k & 1) || d->k / 2 >= d->H || d->k / 2 >= d->W || d->radius < 0) return GA_E_UNSUPPORTED;
+    const int r = (d->radius > 0 && d->radius < d->k / 2) ? d->radius : d->k / 2;
     const size_t lds = ((size_t)2 * d->H * d->W + d->k) * sizeof(float);
-    if (lds > 64 * 1024) return GA_E_UNSUPPORTED;            // planes up to ~90 x 90; larger images are a next row
-    hipLaunchKernelGGL(gauss_blur_kernel, dim3(d->planes), dim3(256), lds, (hipStream_t)s, *d);
+    if (lds <= 64 * 1024) {                                  // the whole plane (both passes) in LDS
+        hipLaunchKernelGGL(gauss_blur_kernel, dim3(d->planes), dim3(256), lds, (hipStream_t)s, *d, r);
+        return check_launch();
+    }
+    if (!d->tmp || d->tmp == d->x || d->tmp == d->y) return GA_E_BADARG;      // two passes through the caller's intermediate planes
+    if (d->H > 4096 || d->W > 4096) return GA_E_UNSUPPORTED;
+    const int RT = 8;
+    int CT = 32;
+    while (CT > 4 && (size_t)d->H * CT * sizeof(float) > 48 * 1024) CT >>= 1;
+    const size_t kpad = ((size_t)d->k + 3) & ~(size_t)3;
+    const size_t lds_x = (kpad + (size_t)RT * d->W) * sizeof(float), lds_y = (kpad + (size_t)d->H * CT) * sizeof(float);
+    if (lds_x > 64 * 1024 || lds_y > 64 * 1024) return GA_E_UNSUPPORTED;
+    const int tx = (d->H + RT - 1) / RT, ty = (d->W + CT - 1) / CT;
+    // forward: along x, then along y (kornia); adjoint: the transposed passes in reverse order
+    if (!d->backward) {
+        hipLaunchKernelGGL(gauss_blur_pass_kernel, dim3(d->planes * tx), dim3(256), lds_x, (hipStream_t)s, d->x, d->tmp, d->taps, d->H, d->W, d->k, r, 0, 0, RT, tx);
+        hipLaunchKernelGGL(gauss_blur_pass_kernel, dim3(d->planes * ty), dim3(256), lds_y, (hipStream_t)s, (const float*)d->tmp, d->y, d->taps, d->H, d->W, d->k, r, 1, 0, CT, ty);
+    } else {
+        hipLaunchKernelGGL(gauss_blur_pass_kernel, dim3(d->planes * ty), dim3(256), lds_y, (hipStream_t)s, d->x, d->tmp, d->taps, d->H, d->W, d->k, r, 1, 1, CT, ty);
+        hipLaunchKernelGGL(gauss_blur_pass_kernel, dim3(d->planes * tx), dim3(256), lds_x, (hipStream_t)s, (const float*)d->tmp, d->y, d->taps, d->H, d->W, d->k, r, 0, 1, RT, tx);
+    }
     return check_launch();
 }
 

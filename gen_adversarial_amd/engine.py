@@ -298,13 +298,18 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             taps = self.devd(f'blur_taps_{k}', lambda: {'g': (g / g.sum()).float()})['g']
             x_src = self.alloc((R // self.rep, 3, H, H))
             dx_dst = self.alloc((R // self.rep, 3, H, H))
+            # sigma 1: taps beyond 12 pixels are < 1e-31 of the peak (the 255-tap kernel of 256-px images has 25 that matter);
+            # planes above ~90 px do not fit LDS and run as two passes through `tmp`
+            tmp = self.alloc((R // self.rep, 3, H, H)) if (2 * H * H + k) * 4 > 64 * 1024 else None
             bl = L.BlurDesc()
             bl.x, bl.y, bl.taps, bl.planes, bl.H, bl.W, bl.k, bl.backward = _ptr(self.x_in), _ptr(x_src), _ptr(taps), (R // self.rep) * 3, H, H, k, 0
+            bl.radius, bl.tmp = min(12, k // 2), _ptr(tmp)
             self.fwd.add(bl, 'gauss_blur')
 
             def bwd_blur():
                 b = L.BlurDesc()
                 b.x, b.y, b.taps, b.planes, b.H, b.W, b.k, b.backward = _ptr(dx_dst), _ptr(self.dx), _ptr(taps), (R // self.rep) * 3, H, H, k, 1
+                b.radius, b.tmp = min(12, k // 2), _ptr(tmp)
                 self.bwd.add(b, 'gauss_blur^T')
             self._bwd_steps.append(bwd_blur)
 

@@ -93,6 +93,11 @@ def gather_results(local: torch.Tensor, world: int, device) -> torch.Tensor:
     return torch.cat(parts, dim=0).cpu()                       # rank-major, like test_defense.py:250-253
 
 
+# results.json column of each attack (test_defense.py:267-287 writes 'Clean', 'DeepFool', 'C&W', 'AutoAttack'; 'PGD' is this
+# build's plug-in and has no reference counterpart)
+RESULT_KEYS = {'deepfool': 'DeepFool', 'c&w': 'C&W', 'autoattack': 'AutoAttack', 'pgd': 'PGD'}
+
+
 def merge_results(path: str, clean: float, columns: Dict[str, List[float]]):
     """read-modify-write of results.json (test_defense.py:255-291)."""
     res = {}
@@ -130,7 +135,7 @@ def run_worker(rank: int, world: int, args, make_model: Callable, dataset: Tuple
     table = gather_results(local, world, dev)
     res = None
     if rank == 0:
-        cols = {name: table[:, 1 + j].tolist() for j, name in enumerate(args.attacks.keys())}
+        cols = {RESULT_KEYS.get(name, name): table[:, 1 + j].tolist() for j, name in enumerate(args.attacks.keys())}
         res = merge_results(results_path or os.path.join(args.results_folder, 'results.json'),
                             float(table[:, 0].mean().item()), cols)
     if world > 1:
@@ -143,20 +148,29 @@ def synthetic_dataset(n: int, size: int, n_classes: int, seed: int = 0):
     return torch.rand(n, 3, size, size, generator=g), torch.randint(0, n_classes, (n,), generator=g)
 
 
+IMAGE_PATTERNS = ('*.png', '*.jpg', '*.bmp', '*.JPEG')
+
+
 def folder_dataset(folder: str, size: int):
-    """<folder>/<class>/<image>: label = index of the parent directory (data/datasets.py:35-58); I/O is outside the
-    accelerated path and kept minimal (PIL + antialiased bilinear resize)."""
+    """ImageLabelDataset (data/datasets.py:35-58): every *.png / *.jpg / *.bmp / *.JPEG below `folder` (recursive), sorted by
+    path; label = index of the image's parent directory name among the sorted names of the directories that HOLD images.
+    I/O is outside the accelerated path and kept minimal (PIL + antialiased bilinear resize = ToTensor + Resize(antialias))."""
+    import pathlib
     from PIL import Image
-    classes = sorted(d for d in os.listdir(folder) if os.path.isdir(os.path.join(folder, d)))
-    xs, ys = [], []
-    for ci, c in enumerate(classes):
-        for f in sorted(os.listdir(os.path.join(folder, c))):
-            im = Image.open(os.path.join(folder, c, f)).convert('RGB')
-            t = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
-            t = torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', antialias=True, align_corners=False)
-            xs.append(t[0])
-            ys.append(ci)
-    return torch.stack(xs), torch.tensor(ys)
+    root = pathlib.Path(folder)
+    samples = sorted(p for pat in IMAGE_PATTERNS for p in root.rglob(pat))
+    samples = [p.absolute().as_posix() for p in samples]
+    if not samples:
+        raise FileNotFoundError(f'no {"/".join(IMAGE_PATTERNS)} images below {folder}')
+    labels_as_str = [p.split('/')[-2] for p in samples]
+    class_names = sorted(set(labels_as_str))
+    xs = []
+    for f in samples:
+        im = Image.open(f).convert('RGB')
+        t = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1).unsqueeze(0)
+        t = torch.nn.functional.interpolate(t, size=(size, size), mode='bilinear', antialias=True, align_corners=False)
+        xs.append(t[0])
+    return torch.stack(xs), torch.tensor([class_names.index(s_) for s_ in labels_as_str])
 
 
 def parse_args(argv=None):

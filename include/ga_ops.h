@@ -341,10 +341,16 @@ int ga_image_io(const ga_image_io_desc* d, void* stream);
 /* Separable Gaussian blur of image planes with 'reflect' border (kornia.filters.gaussian_blur2d as called by
  * MLVGMDefenseModel.apply_gaussian_blur, src/defenses/ours/abstract_models.py:145-159: k = 2^(sqrt(H)//2) - 1 taps,
  * sigma 1).  x, y: [planes][H][W] (NCHW images seen as N*C planes); taps: [k] normalised weights, k odd, k/2 < H, W.
- * backward = the exact adjoint (reflect padding included): given dy in `x`, writes dx to `y`. */
+ * backward = the exact adjoint (reflect padding included): given dy in `x`, writes dx to `y`.
+ * Small planes run as one kernel with the plane in LDS; larger ones as two passes (rows, then column strips) through `tmp`. */
 typedef struct ga_blur_desc {
     const float* x; float* y; const float* taps;
     int planes, H, W, k; int backward;
+    int radius;               /* > 0: taps farther than `radius` from the centre are skipped — the caller asserts that they lie
+                                 below the fp32 resolution of the result (sigma 1: exp(-r^2/2) < 1e-31 at r = 12; the reference's
+                                 255-tap kernel at 256 px has 25 such taps).  0: all k taps */
+    float* tmp;               /* intermediate planes [planes][H][W] for planes too large to blur inside LDS ((2 H W + k) * 4 >
+                                 64 KB, i.e. above ~90 x 90: the 128-px cars and 256-px gender images); may be NULL otherwise */
 } ga_blur_desc;
 int ga_gauss_blur(const ga_blur_desc* d, void* stream);
 
@@ -418,6 +424,11 @@ int ga_graph_destroy(void* graph);
 
 /* per-op device time (ms) of one replay: per_op_ms[n] written */
 int ga_plan_profile(const ga_op* ops, int n, void* stream, float* per_op_ms);
+
+/* testing hook: ga_conv2d convolves row sub-batches once one of its per-row operands passes 2 GB (the fast loaders' 31-bit
+ * offsets); this lowers that limit so that the sub-batch path can be exercised at small sizes.  bytes <= 0 restores the
+ * default; returns the previous value. */
+long ga_debug_set_conv_row_limit(long bytes);
 
 const char* ga_last_hip_error(void);
 int ga_abi_version(void);

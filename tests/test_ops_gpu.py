@@ -817,6 +817,40 @@ def test_gauss_blur_forward_and_adjoint(H, k):
     close(dx, gx, 1e-6, 'blur adjoint')
 
 
+@pytest.mark.parametrize('H,W,k,radius', [(128, 128, 31, 0), (128, 128, 31, 12), (256, 256, 255, 12), (96, 200, 15, 0)])
+def test_gauss_blur_large_planes_two_pass(H, W, k, radius):
+    """the real image sizes of the cars (128 px, k = 31) and gender (256 px, k = 255) experiments
+    (abstract_models.py:150-158): planes beyond LDS run as two passes through `tmp`; `radius` 12 skips taps below 1e-31 of
+    the peak.  Forward and exact adjoint against the oracle's kornia restatement."""
+    from oracle import defender_oracle as D
+    x = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(1))
+    taps = D.gaussian_kernel1d(k)
+    xr = x.clone().requires_grad_(True)
+    p = k // 2
+    y = F.pad(xr, (p, p, p, p), mode='reflect')
+    y = F.conv2d(y, taps.view(1, 1, 1, k).expand(3, 1, 1, k), groups=3)
+    ref = F.conv2d(y, taps.view(1, 1, k, 1).expand(3, 1, k, 1), groups=3)
+    if H == W and k == D.blur_kernel_size(H):
+        np.testing.assert_allclose(D.apply_gaussian_blur(x).numpy(), ref.detach().numpy(), atol=1e-6)
+    xd, td = x.to(DEV), taps.to(DEV)
+    out, tmp = torch.empty_like(xd), torch.empty_like(xd)
+    d = L.BlurDesc()
+    d.x, d.y, d.taps, d.planes, d.H, d.W, d.k = xd.data_ptr(), out.data_ptr(), td.data_ptr(), 6, H, W, k
+    d.radius, d.tmp = radius, tmp.data_ptr()
+    L.run(d)
+    close(out, ref, 1e-6, 'blur fwd (two-pass)')
+    cot = g(2, 3, H, W, seed=2)
+    (gx,) = torch.autograd.grad((ref * cot).sum(), [xr])
+    cd = cot.to(DEV)
+    dx = torch.empty_like(xd)
+    d.x, d.y, d.backward = cd.data_ptr(), dx.data_ptr(), 1
+    L.run(d)
+    close(dx, gx, 1e-6, 'blur adjoint (two-pass)')
+    d.tmp = None                                              # a large plane without the intermediate buffer is rejected
+    with pytest.raises(L.GaError):
+        L.run(d)
+
+
 def test_rep_sum_and_shared_addend():
     rows, rep, inner = 12, 4, 40
     x = g(rows, inner, seed=1).to(DEV)
@@ -909,6 +943,53 @@ def test_conv_beyond_2gb_runs_in_row_sub_batches():
     assert torch.equal(whole, rows)
     ref = torch.einsum('nhc,oc->nho', (x[:, 500, :64] * sc[:, None, :]).double(), w.double()) + add[:, 500, :64].double()
     assert (whole[:, 500, :64].double() - ref).abs().max().item() < 1e-3
+
+
+def test_conv_sub_batches_with_every_per_row_operand():
+    """the row sub-batch path of ga_conv2d (taken above 2 GB; forced here with ga_debug_set_conv_row_limit) with a per-row
+    prologue, an addend shared by `addend_rep` consecutive rows (EoT replicas reading one encoder feature map), a second
+    addend and an act' source: bitwise equal to the single launch"""
+    N, H, C, Co, rep = 12, 16, 64, 32, 3
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(N, H, H, C, device=DEV, generator=gen)
+    w = (torch.randn(Co, 9 * C, device=DEV, generator=gen) / (9 * C) ** 0.5).contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    sc = (1.0 + 0.1 * torch.randn(N, C, device=DEV, generator=gen)).contiguous()
+    sh = (0.1 * torch.randn(N, C, device=DEV, generator=gen)).contiguous()
+    add = torch.randn(N // rep, H, H, Co, device=DEV, generator=gen)
+    add2 = torch.randn(N, H, H, Co, device=DEV, generator=gen)
+    dact = torch.randn(N, H, H, Co, device=DEV, generator=gen)
+
+    def run(out, precise):
+        d = L.ConvDesc()
+        d.x, d.ldx, d.C1, d.w = x.data_ptr(), C, C, w.data_ptr()
+        if not precise:
+            d.w_hi, d.w_lo = hi.data_ptr(), lo.data_ptr()
+        d.pro_scale, d.pro_shift, d.pro_per_row = sc.data_ptr(), sh.data_ptr(), 1
+        d.y, d.ldy, d.Cout = out.data_ptr(), Co, Co
+        d.addend, d.ldadd, d.addend_rep = add.data_ptr(), Co, rep
+        d.addend2, d.ldadd2 = add2.data_ptr(), Co
+        d.dact_x, d.lddact, d.dact_act = dact.data_ptr(), Co, L.GA_ACT_SILU
+        d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad = N, H, H, H, H, 3, 3, 1, 1, 1
+        L.run(d, torch.cuda.current_stream().cuda_stream)
+
+    for precise in (True, False):
+        whole, parts = torch.zeros(N, H, H, Co, device=DEV), torch.zeros(N, H, H, Co, device=DEV)
+        run(whole, precise)
+        row_bytes = H * H * C * 4
+        old = L.lib.ga_debug_set_conv_row_limit(4 * row_bytes + 1)          # sub = 4 rows -> rounded down to 3 (a multiple of rep)
+        try:
+            run(parts, precise)
+        finally:
+            L.lib.ga_debug_set_conv_row_limit(old)
+        assert torch.equal(whole, parts)
+    # and against plain torch (fp32 path)
+    xs = x * sc[:, None, None, :] + sh[:, None, None, :]
+    ref = F.conv2d(xs.permute(0, 3, 1, 2), w.view(Co, 3, 3, C).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    sg = torch.sigmoid(dact)
+    ref = ref * (sg * (1 + dact * (1 - sg))) + add.repeat_interleave(rep, dim=0) + add2
+    close(whole, ref.cpu(), 1e-3, 'sub-batched conv vs torch')
 
 
 def test_halo_tiles_refuse_unsupported_shapes():

@@ -139,3 +139,29 @@ def test_gender_ablation_defenders_see_the_preprocessed_image(tmp_path):
             assert (m.model(x.to(DEV)).cpu() - ref).abs().max().item() < 1e-3
         else:
             assert abs((p.cpu() - x).flatten(1).norm(dim=1).max().item() - 4.0) < 0.4      # L2 = eps (4.0 for gender) before the clamp
+
+
+def test_blur_ablation_at_256px_matches_oracle():
+    """GaussianBlurDefenseModel of the gender experiment (src/defenses/ablations/models.py:42-66; kernel 255 taps at 256 px,
+    abstract_models.py:150-158) in front of a reduced ResNet: the two-pass blur kernel inside an engine, forward + adjoint"""
+    from oracle import defender_oracle as D
+    from gradcheck import assert_grad_given_engine_decisions
+    spec = build_resnet_spec(2, 8, (1, 1, 1, 1))
+    sd = init_resnet_state_dict(2, 8, 7, (1, 1, 1, 1))
+    gen = torch.Generator().manual_seed(5)
+    rows = 2
+    x = torch.rand(rows, 3, 256, 256, generator=gen)
+    cot = torch.randn(rows, 2, generator=gen)
+    eng = Engine(None, None, (3, 256, 256), sd, spec, rows=rows, rep=1, alphas=[], device=DEV, precision='bf16x3', blur=True)
+    assert 'gauss_blur' in eng.fwd.names and 'gauss_blur^T' in eng.bwd.names
+    eng.x_in.copy_(x.to(DEV))
+    eng.forward()
+    ref = D.resnet_classifier_call(sd, spec, D.apply_gaussian_blur(x))
+    e_l = (eng.logits.cpu() - ref).abs().max().item()
+    e_b = (eng.input_image_nchw().cpu() - D.apply_gaussian_blur(x)).abs().max().item()
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    print(f'blur ablation 256 px: blurred image err {e_b:.2e}, logits err {e_l:.2e}')
+    assert e_b < 1e-5 and e_l < 1e-3
+    assert_grad_given_engine_decisions(eng, lambda t: (D.resnet_classifier_call(sd, spec, D.apply_gaussian_blur(t)) * cot).sum(), x, eng.dx,
+                                       1e-3, 'input gradient through blur + ResNet', min_matched=8)
