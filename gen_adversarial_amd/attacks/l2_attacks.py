@@ -17,7 +17,13 @@ What differs from the reference, deliberately:
     accumulate weight gradients that nobody reads (SURVEY.md §3.1);
   * DeepFool / FAB need one input-gradient per class on the SAME forward: they go through `class_gradients`, which issues
     the vector-Jacobian products back to back on one retained graph (the HIP defender replays its backward plan per call).
-Random draws use `torch.randn_like(image)` in the reference's order, so a CPU run under `torch.manual_seed` reproduces
+  * DeepFool, FAB, APGD, AutoAttack and FGSM are BATCHED over images (`batched = True`): `image` may be
+    (B,3,H,W) with `gt_label` (B,), every image attacked independently — per-sample norms, masks, early exits, step sizes and
+    bests — while every defender call carries B x EoT rows and every per-class backward pass serves all B images at once
+    (one vector-Jacobian pass per class RANK for the whole batch: untargeted.py:526-560, :605-635 issue them per image).  For
+    B = 1 the arithmetic is the reference's, operation for operation (tests/golden/attacks_toy.npz); for B > 1 every image's
+    result equals its own B = 1 run (tests/test_attacks_cpu.py).  C&W keeps the one-image protocol.
+Random draws use `torch.randn_like` per image in the reference's order, so a CPU run under `torch.manual_seed` reproduces
 the reference bit for bit (tests/golden/attacks_*.npz).
 """
 from __future__ import annotations
@@ -41,18 +47,41 @@ class UntargetedL2Attack(ABC):
 
 
 def class_gradients(net: nn.Module, x: torch.Tensor, classes=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ONE forward, then d logits[0, k] / d x for every k in `classes` (all classes when None): logits (1, n) and the
-    gradients stacked (len(classes), *x.shape[1:]).  With a stochastic defender every gradient belongs to the same draw."""
+    """ONE forward of the whole batch, then d logits[b, k_b] / d x_b: logits (B, n) and the gradients (B, K, *x.shape[1:]).
+    classes: None (all n classes, the same for every image) or a (B, K) index tensor (each image its own class list).  One
+    backward pass per class COLUMN serves all B images (they are independent rows of the defender).  With a stochastic
+    defender every gradient belongs to the same draw."""
     x = x.detach().clone().requires_grad_(True)
     with torch.enable_grad():
         y = net(x)
-        ks = range(y.shape[1]) if classes is None else classes
-        grads = [torch.autograd.grad(y[0, int(k)], [x], retain_graph=True)[0][0] for k in ks]
-    return y.detach(), torch.stack(grads, dim=0)
+        if classes is None:
+            cols = [y[:, k].sum() for k in range(y.shape[1])]
+        else:
+            cols = [y.gather(1, classes[:, j:j + 1]).sum() for j in range(classes.shape[1])]
+        grads = [torch.autograd.grad(c, [x], retain_graph=True)[0] for c in cols]
+    return y.detach(), torch.stack(grads, dim=1)
+
+
+def _per_image_randn(image: torch.Tensor) -> torch.Tensor:
+    """N(0,1) noise drawn image by image (the order B one-image attacks would draw it in)"""
+    return torch.cat([torch.randn_like(image[b:b + 1]) for b in range(image.shape[0])], dim=0)
+
+
+def _ret(success: torch.Tensor, bound: torch.Tensor, adv: torch.Tensor):
+    """the protocol's (bool, float, adv) for one image; tensors (B,), (B,), (B,...) for a batch"""
+    if adv.shape[0] == 1:
+        return bool(success.item()), float(bound.item()), adv
+    return success, bound, adv
+
+
+def _bc(v: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    return v.view(-1, *([1] * (like.dim() - 1)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 class FGSM(UntargetedL2Attack):
+    batched = True
+
     def __init__(self, l2_bound: float):
         self.l2_bound = l2_bound
 
@@ -60,57 +89,67 @@ class FGSM(UntargetedL2Attack):
         x = image.detach().clone().requires_grad_(True)
         with torch.enable_grad():
             logits = net(x)
-            if torch.argmax(logits, dim=-1) != gt_label:
-                return True, 0.0, image
-            cost = -nn.functional.cross_entropy(logits, gt_label)
+            already = torch.argmax(logits, dim=-1) != gt_label.view(-1)
+            if bool(already.all()):
+                return _ret(already, torch.zeros(x.shape[0], device=x.device), image)
+            cost = -nn.functional.cross_entropy(logits, gt_label.view(-1), reduction='sum')     # per-image gradients: rows are independent
             (g,) = torch.autograd.grad(cost, [x])
         step = g.sign()
         step = step / torch.norm(step.view(step.size(0), -1), p=2, dim=1, keepdim=True).view(-1, 1, 1, 1)
         x_adv = torch.clamp(x.detach() - step * self.l2_bound, 0., 1.)
         with torch.no_grad():
-            fooled = torch.argmax(net(x_adv), dim=-1) != gt_label
-        return fooled, self.l2_bound, x_adv.detach()
+            fooled = torch.argmax(net(x_adv), dim=-1) != gt_label.view(-1)
+        x_adv = torch.where(_bc(already, x_adv), image.detach(), x_adv)
+        bound = torch.where(already, torch.zeros_like(fooled, dtype=torch.float32), torch.full_like(fooled, self.l2_bound, dtype=torch.float32))
+        return _ret(fooled | already, bound, x_adv.detach())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 class DeepFool(UntargetedL2Attack):
+    batched = True
+
     def __init__(self, num_classes=10, overshoot=0.02, max_iter=50):
         self.num_classes, self.overshoot, self.max_iter = num_classes, overshoot, max_iter
 
     def __call__(self, image, gt_label, net):
+        B = image.shape[0]
+        ar = torch.arange(B, device=image.device)
+        gt = gt_label.view(-1)
         with torch.no_grad():
-            f0 = net(image).flatten()
-        ranked = torch.argsort(f0, descending=True)[:self.num_classes]
-        label = int(ranked[0])
-        if int(gt_label) != label:
-            return True, 0.0, image.detach()                       # already misclassified: nothing to attack
-
+            f0 = net(image)
+        ranked = torch.argsort(f0, dim=1, descending=True)[:, :self.num_classes]          # (B, K): each image its own top classes
+        label = ranked[:, 0]
+        already = gt != label                                                              # misclassified at the start: nothing to attack
+        active = ~already
         r_tot = torch.zeros_like(image, dtype=torch.float32)
         pert_image = image.clone()
-        k_i, it = label, 0
-        x = pert_image.detach().clone().requires_grad_(True)
-        with torch.enable_grad():
-            fs = net(x)                                            # one forward per iteration: decision AND gradients
-        while k_i == label and it < self.max_iter:
-            with torch.enable_grad():
-                grads = torch.stack([torch.autograd.grad(fs[0, int(k)], [x], retain_graph=True)[0][0] for k in ranked])
-            w_k = grads[1:] - grads[0:1]                           # (k-1, C, H, W) float32
-            f_k = (fs.detach()[0, ranked[1:]] - fs.detach()[0, ranked[0]]).abs()
-            dist = f_k / w_k.flatten(1).norm(dim=1)
-            j = int(torch.argmin(dist))                            # first minimum, like the reference's strict '<' scan
-            w = w_k[j]
-            r_i = (dist[j] + 1e-4) * w / w.flatten().norm()
-            r_tot = (r_tot.double() + r_i.double().unsqueeze(0)).float()      # float64 accumulate, float32 keep (:549-550)
-            pert_image = image + (1 + self.overshoot) * r_tot
-            x = pert_image.detach().clone().requires_grad_(True)
-            with torch.enable_grad():
-                fs = net(x)
-            k_i = int(torch.argmax(fs.detach().flatten()))
+        k_i, it = label.clone(), 0
+        while bool(active.any()) and it < self.max_iter:
+            # one forward per iteration (decision AND gradients), one backward pass per class rank for the whole batch
+            fs, grads = class_gradients(net, pert_image, ranked)                          # (B, n), (B, K, C, H, W)
+            if it > 0:
+                k_i = torch.where(active, fs.argmax(dim=1), k_i)
+                active = active & (k_i == label)
+                if not bool(active.any()):
+                    break
+            w_k = grads[:, 1:] - grads[:, 0:1]                                             # (B, K-1, C, H, W) float32
+            f_k = (fs.gather(1, ranked[:, 1:]) - fs.gather(1, ranked[:, :1])).abs()
+            dist = f_k / w_k.flatten(2).norm(dim=2)
+            j = torch.argmin(dist, dim=1)                                                  # first minimum, like the reference's strict '<' scan
+            w = w_k[ar, j]
+            r_i = _bc(dist[ar, j] + 1e-4, w) * w / _bc(w.flatten(1).norm(dim=1), w)
+            r_new = (r_tot.double() + r_i.double()).float()                                # float64 accumulate, float32 keep (:549-550)
+            r_tot = torch.where(_bc(active, r_tot), r_new, r_tot)
+            pert_image = torch.where(_bc(active, r_tot), image + (1 + self.overshoot) * r_tot, pert_image)
             it += 1
-        if k_i == int(gt_label):
-            return False, float('inf'), image.detach()
-        r_fin = (1 + self.overshoot) * r_tot
-        return True, float(r_fin.flatten().norm()), pert_image.detach()
+        if bool(active.any()):                                                             # the decision after the last step
+            with torch.no_grad():
+                k_i = torch.where(active, net(pert_image).argmax(dim=1), k_i)
+        fooled = (k_i != gt) & ~already
+        r_fin = ((1 + self.overshoot) * r_tot).flatten(1).norm(dim=1)
+        bound = torch.where(already, torch.zeros_like(r_fin), torch.where(fooled, r_fin, torch.full_like(r_fin, float('inf'))))
+        adv = torch.where(_bc(fooled, image), pert_image, image).detach()
+        return _ret(fooled | already, bound, adv)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -178,6 +217,8 @@ class CW(UntargetedL2Attack):
 
 # ---------------------------------------------------------------------------------------------------------------------
 class APGDAttack(UntargetedL2Attack):
+    batched = True
+
     def __init__(self, n_iter: int, rho: float, max_bound: float, ce_loss: bool):
         self.n_iter, self.rho, self.max_bound = n_iter, rho, max_bound
         self.criterion = nn.CrossEntropyLoss(reduction='none') if ce_loss else self.dlr_loss
@@ -187,42 +228,47 @@ class APGDAttack(UntargetedL2Attack):
         self.step_size_decr = max(int(0.03 * n_iter), 1)
 
     def dlr_loss(self, logits, gt_label):
-        """-(z_y - max_{j != y} z_j) / (z_(1) - z_(3)), with the reference's guard when z_(3) is the true class (:86-123)."""
+        """-(z_y - max_{j != y} z_j) / (z_(1) - z_(3)), with the reference's guard when z_(3) is the true class (:86-123);
+        per image"""
         if logits.shape[1] < 4:
             raise AttributeError('APGD_DLR is undefined for problems with less than 4 classes!')
+        gt = gt_label.view(-1)
         srt, idx = logits.sort(dim=1)
-        still_correct = bool(torch.eq(idx[:, -1], gt_label).item())
-        z_y = logits[0, gt_label]
-        z_other = srt[:, -2] if still_correct else srt[:, -1]
-        third = srt[:, -3] if bool(torch.ne(srt[:, -3], z_y)) else srt[:, -4]
+        still_correct = torch.eq(idx[:, -1], gt)
+        z_y = logits.gather(1, gt.view(-1, 1)).squeeze(1)
+        z_other = torch.where(still_correct, srt[:, -2], srt[:, -1])
+        third = torch.where(torch.ne(srt[:, -3], z_y), srt[:, -3], srt[:, -4])
         return -(z_y - z_other) / (srt[:, -1] - third + self.division_eps)
 
     def _loss_and_grad(self, net, x, label):
         x = x.detach().requires_grad_(True)
         with torch.enable_grad():
-            loss = self.criterion(net(x), label)
-            (g,) = torch.autograd.grad(loss, [x])
-        return x, loss, g.detach()
+            loss = self.criterion(net(x), label.view(-1))                   # (B,): rows are independent, so the gradient of the
+            (g,) = torch.autograd.grad(loss.sum(), [x])                    # sum holds every image's own gradient
+        return x, loss.detach(), g.detach()
 
     def _project(self, delta):
         """onto the L2 ball of radius max_bound (per sample)"""
         return normalize(delta) * torch.min(self.max_bound * torch.ones_like(delta), l2_norm(delta, keepdim=True))
 
     def _stalled(self, losses, step, lookback):
-        window = losses[step - (lookback - 1): step + 1]
+        window = losses[step - (lookback - 1): step + 1]                    # (lookback, B)
         prev = torch.roll(window, shifts=1, dims=0)
         prev[0] = window[0]
-        return torch.gt(window, prev).sum().item() < lookback * self.rho
+        return torch.gt(window, prev).sum(dim=0) < lookback * self.rho
 
-    def __call__(self, image, gt_label, net):
-        x_adv = (image + self.max_bound * normalize(torch.randn_like(image))).clamp(0., 1.)
+    def __call__(self, image, gt_label, net, init_noise: torch.Tensor = None):
+        """init_noise: the N(0,1) draw of the random start (B,3,H,W); None draws it image by image"""
+        B = image.shape[0]
+        noise = _per_image_randn(image) if init_noise is None else init_noise
+        x_adv = (image + self.max_bound * normalize(noise)).clamp(0., 1.)
         x_prev = x_adv.clone()
         x_adv, loss, grad = self._loss_and_grad(net, x_adv, gt_label)
-        step = 2 * self.max_bound
+        step = torch.full((B,), 2 * self.max_bound, device=image.device, dtype=image.dtype)
         since_check, check_every = 0, self.initial_step_size_iters
-        losses = torch.zeros([self.n_iter, 1], device=image.device)
-        reduced_last = True
-        best_loss = prev_best = loss.item()
+        losses = torch.zeros([self.n_iter, B], device=image.device)
+        reduced_last = torch.ones(B, dtype=torch.bool, device=image.device)
+        best_loss, prev_best = loss.clone(), loss.clone()
         x_best, g_best = x_adv.clone(), grad.clone()
         for i in range(self.n_iter):
             with torch.no_grad():
@@ -230,79 +276,94 @@ class APGDAttack(UntargetedL2Attack):
                 momentum = x_adv - x_prev
                 x_prev = x_adv.clone()
                 a = 0.75 if i > 0 else 1.0
-                z = torch.clamp(image + self._project(x_adv + step * normalize(grad) - image), 0., 1.)
+                z = torch.clamp(image + self._project(x_adv + _bc(step, image) * normalize(grad) - image), 0., 1.)
                 z = x_adv + (z - x_adv) * a + momentum * (1 - a)
                 x_adv = torch.clamp(image + self._project(z - image), 0., 1.)
             x_adv, loss, grad = self._loss_and_grad(net, x_adv, gt_label)
             with torch.no_grad():
-                lv = loss.item()
-                losses[i] = lv
-                if lv > best_loss:
-                    best_loss, x_best, g_best = lv, x_adv.clone(), grad.clone()
+                losses[i] = loss
+                better = loss > best_loss
+                best_loss = torch.where(better, loss, best_loss)
+                x_best = torch.where(_bc(better, x_adv), x_adv, x_best)
+                g_best = torch.where(_bc(better, grad), grad, g_best)
                 since_check += 1
                 if since_check == check_every:
-                    halve = self._stalled(losses, i, since_check) or (prev_best >= best_loss and not reduced_last)
-                    reduced_last, prev_best = halve, best_loss
-                    if halve:
-                        step /= 2.0
-                        x_adv, grad = x_best.clone(), g_best.clone()
+                    halve = self._stalled(losses, i, since_check) | ((prev_best >= best_loss) & ~reduced_last)
+                    reduced_last, prev_best = halve, best_loss.clone()
+                    step = torch.where(halve, step / 2.0, step)
+                    x_adv = torch.where(_bc(halve, x_adv), x_best, x_adv)
+                    grad = torch.where(_bc(halve, grad), g_best, grad)
                     since_check = 0
                     check_every = max(check_every - self.step_size_decr, self.min_step_size_iters)
         with torch.no_grad():
-            ok = torch.ne(net(x_adv).argmax(dim=1), gt_label).item()
-        bound = torch.linalg.norm((x_adv.detach() - image.detach()).flatten(), ord=2).item()
-        return ok, bound, x_adv.detach()
+            ok = torch.ne(net(x_adv).argmax(dim=1), gt_label.view(-1))
+        bound = (x_adv.detach() - image.detach()).flatten(1).norm(dim=1)
+        return _ret(ok, bound, x_adv.detach())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 class FABAttack(UntargetedL2Attack):
+    batched = True
+
     def __init__(self, n_iter: int, alpha_max: float, eta: float, beta: float):
         self.n_iter, self.eta, self.beta, self.alpha_max = n_iter, eta, beta, alpha_max
 
     def get_diff_logits_grads(self, image, label, net):
-        """logit differences to the true class and their input-gradients, all classes from one forward (:605-635)."""
-        y, g = class_gradients(net, image)                          # g: (n_classes, C, H, W)
-        g = g.unsqueeze(0)                                           # (1, n_classes, C, H, W)
-        df = y - y[:, label]
-        dg = g - g[:, label]
-        df[:, label] = 1e10
+        """logit differences to the true class and their input-gradients, all classes from ONE forward of the batch and one
+        backward pass per class for all images (:605-635 loops over the classes per image)"""
+        y, g = class_gradients(net, image)                          # (B, n), (B, n, C, H, W)
+        ar = torch.arange(y.shape[0], device=y.device)
+        df = y - y[ar, label].unsqueeze(1)
+        dg = g - g[ar, label].unsqueeze(1)
+        df[ar, label] = 1e10
         return df, dg
 
     def __call__(self, image, gt_label, net):
         image = image.detach().clone()
+        B = image.shape[0]
+        ar = torch.arange(B, device=image.device)
+        gt = gt_label.view(-1)
         with torch.no_grad():
-            if torch.argmax(net(image)) != gt_label:
-                return True, 0.0, image.detach()
-        x_adv, bound, ok = image.clone(), 1e10, False
+            already = net(image).argmax(dim=1) != gt
+        if bool(already.all()):
+            return _ret(already, torch.zeros(B, device=image.device), image.detach())
+        x_adv = image.clone()
+        bound = torch.full((B,), 1e10, device=image.device)
+        ok = torch.zeros(B, dtype=torch.bool, device=image.device)
         x_orig, x_i = image.clone(), image.clone()
-        flat_orig = image.clone().view(1, -1)
+        flat_orig = image.clone().view(B, -1)
         for _ in range(self.n_iter):
-            df, dg = self.get_diff_logits_grads(x_i, gt_label, net)
+            df, dg = self.get_diff_logits_grads(x_i, gt, net)
             with torch.no_grad():
-                dist = df.abs() / (1e-12 + (dg ** 2).reshape(1, df.shape[1], -1).sum(dim=-1).sqrt())
-                s = dist.min(dim=1).indices                                   # closest decision hyperplane
-                dg_s = dg[:, s]
-                b = -df[:, s] + (dg_s * x_i).view(1, -1).sum(dim=-1)
-                w = dg_s.view([1, -1])
-                d3 = projection_l2(torch.cat((x_i.view(1, -1), flat_orig), 0), torch.cat((w, w), 0), torch.cat((b, b), 0))
-                d_i, d_o = torch.reshape(d3[:1], x_i.shape), torch.reshape(d3[-1:], x_i.shape)
+                dist = df.abs() / (1e-12 + (dg ** 2).reshape(B, df.shape[1], -1).sum(dim=-1).sqrt())
+                s = dist.min(dim=1).indices                                   # closest decision hyperplane, per image
+                dg_s = dg[ar, s]
+                b = -df[ar, s] + (dg_s * x_i).view(B, -1).sum(dim=-1)
+                w = dg_s.view(B, -1)
+                d3 = projection_l2(torch.cat((x_i.view(B, -1), flat_orig), 0), torch.cat((w, w), 0), torch.cat((b, b), 0).unsqueeze(1))
+                d_i, d_o = torch.reshape(d3[:B], x_i.shape), torch.reshape(d3[B:], x_i.shape)
                 a0 = (d3 ** 2).sum(dim=1, keepdim=True).sqrt().view(-1, 1, 1, 1)
                 a0 = torch.max(a0, 1e-8 * torch.ones_like(a0))
-                a1, a2 = a0[:1], a0[-1:]
+                a1, a2 = a0[:B], a0[B:]
                 alpha = torch.min(torch.max(a1 / (a1 + a2), torch.zeros_like(a1)), self.alpha_max * torch.ones_like(a1))
                 x_i = ((x_i + self.eta * d_i) * (1 - alpha) + (x_orig + d_o * self.eta) * alpha).clamp(0.0, 1.0)
-                if torch.ne(net(x_i).argmax(dim=1), gt_label).item():
-                    ok = True
-                    t = ((x_i - x_orig) ** 2).view(1, -1).sum(dim=-1).sqrt().item()
-                    if t < bound:
-                        x_adv, bound = x_i.clone(), t
-                    x_i = (1 - self.beta) * x_orig + self.beta * x_i          # step back towards the original
-        return ok, bound, x_adv.detach()
+                fooled = torch.ne(net(x_i).argmax(dim=1), gt) & ~already
+                ok = ok | fooled
+                t = ((x_i - x_orig) ** 2).view(B, -1).sum(dim=-1).sqrt()
+                improve = fooled & (t < bound)
+                x_adv = torch.where(_bc(improve, x_adv), x_i, x_adv)
+                bound = torch.where(improve, t, bound)
+                x_i = torch.where(_bc(fooled, x_i), (1 - self.beta) * x_orig + self.beta * x_i, x_i)   # step back towards the original
+        ok = ok | already
+        bound = torch.where(already, torch.zeros_like(bound), bound)
+        return _ret(ok, bound, x_adv.detach())
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 class AutoAttack(UntargetedL2Attack):
-    """APGD-CE at bounds .5/1/4, APGD-DLR at .5/2/4 (when > 3 classes), FAB; smallest successful distortion wins."""
+    """APGD-CE at bounds .5/1/4, APGD-DLR at .5/2/4 (when > 3 classes), FAB; smallest successful distortion wins.  Batched:
+    an image leaves an escalation as soon as one bound succeeds for it, the remaining images go on as a smaller batch."""
+    batched = True
 
     def __init__(self):
         mk = lambda bound, ce: APGDAttack(n_iter=64, rho=0.75, max_bound=bound, ce_loss=ce)   # noqa: E731
@@ -311,27 +372,41 @@ class AutoAttack(UntargetedL2Attack):
         self.fab = FABAttack(n_iter=128, alpha_max=0.1, eta=1.05, beta=0.9)
 
     @staticmethod
+    def _tensors(res, image):
+        s, b, a = res
+        if not torch.is_tensor(s):
+            s = torch.tensor([bool(s)], device=image.device)
+            b = torch.tensor([float(b)], device=image.device)
+        return s.clone(), b.clone().float(), a.clone()
+
+    @staticmethod
     def _better(cur, new):
+        """per image: a success replaces a failure (:267-285); between two successes the smaller distortion wins"""
         (s0, b0, a0), (s1, b1, a1) = cur, new
-        if s1 and not s0:
-            return new
-        if s1 and s0 and b1 < b0:
-            return s0, b1, a1
-        return cur
+        first = s1 & ~s0
+        smaller = s1 & s0 & (b1 < b0)
+        take = first | smaller
+        return s0 | s1, torch.where(take, b1, b0), torch.where(_bc(take, a0), a1, a0)
 
     def _escalate(self, attacks: List[APGDAttack], image, label, net):
-        """try increasing bounds until one succeeds (:288-296, :307-316)"""
-        res = attacks[0](image, label, net)
+        """try increasing bounds until one succeeds (:288-296, :307-316), image by image"""
+        res = self._tensors(attacks[0](image, label, net), image)
         for atk in attacks[1:]:
-            if res[0]:
+            todo = (~res[0]).nonzero().flatten()
+            if todo.numel() == 0:
                 break
-            res = self._better(res, atk(image, label, net))
+            sub = self._tensors(atk(image[todo], label.view(-1)[todo], net), image)
+            s, b, a = res
+            bs, bb, ba = self._better((s[todo], b[todo], a[todo]), sub)
+            s[todo], b[todo], a[todo] = bs, bb, ba
+            res = (s, b, a)
         return res
 
     def __call__(self, image, gt_label, net):
         best = self._escalate(self.ce, image, gt_label, net)
         with torch.no_grad():
-            n_classes = net(image).shape[1]
+            n_classes = net(image[:1]).shape[1]
         if n_classes > 3:
             best = self._better(best, self._escalate(self.dlr, image, gt_label, net))
-        return self._better(best, self.fab(image, gt_label, net))
+        best = self._better(best, self._tensors(self.fab(image, gt_label, net), image))
+        return _ret(*best)

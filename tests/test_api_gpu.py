@@ -222,3 +222,39 @@ def test_ablation_defenders_and_alpha_objective(setup, tmp_path):
     assert 0.0 <= acc <= 1.0
     al, ac = random_search(ev, 2, seed=1)
     assert al.shape == (2, 6) and ac.shape == (2, 1)
+
+
+def test_batched_deepfool_and_fab_equal_the_one_image_protocol(setup):
+    """SURVEY.md §8 row f1 on the HIP defender: DeepFool / FAB over B = 3 images in one call (3 x EoT rows per defender run,
+    one backward pass per class rank for all images) against the reference's one-image-at-a-time protocol.  The defender is
+    made deterministic for the comparison (alpha = 0 everywhere: no latent noise enters; the input noise is fixed), so both
+    runs see the same function."""
+    from gen_adversarial_amd.attacks.l2_attacks import DeepFool, FABAttack
+    args, model, ck, vsd, alphas = setup
+    old = list(model.model.interpolation_alphas)
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(3, *RES, generator=g).to(DEV)
+    spec = build_spec(CFG, RES)
+    try:
+        model.model.interpolation_alphas[:] = [0.0] * len(old)
+
+        def fix(rows):          # equal input noise for every image: row r of any call uses draw r % EOT
+            n = torch.randn(EOT, *RES, generator=torch.Generator().manual_seed(9)).to(DEV)
+            eps = [torch.zeros(rows, 4, gs.res, gs.res, device=DEV) for gs in spec.groups]
+            model.model.fixed_noise(eps, n.repeat(rows // EOT, 1, 1, 1))
+        fix(3 * EOT)
+        with torch.no_grad():
+            labels = model(x).argmax(dim=1)
+        for mk in (lambda: DeepFool(num_classes=4, overshoot=0.02, max_iter=4), lambda: FABAttack(n_iter=3, alpha_max=0.1, eta=1.05, beta=0.9)):
+            fix(3 * EOT)
+            s, b, a = mk()(x, labels, model)
+            for i in range(3):
+                fix(EOT)
+                s1, b1, a1 = mk()(x[i:i + 1], labels[i:i + 1], model)
+                assert bool(s[i]) == bool(s1), (type(mk()).__name__, i)
+                if bool(s1):
+                    assert abs(float(b[i]) - float(b1)) <= 2e-3 * max(1.0, float(b1)), (type(mk()).__name__, i, float(b[i]), float(b1))
+                assert (a[i:i + 1] - a1).abs().max().item() < 2e-3
+    finally:
+        model.model.interpolation_alphas[:] = old
+        model.model.fixed_noise(None, None)

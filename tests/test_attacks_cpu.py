@@ -80,3 +80,75 @@ def test_dlr_needs_four_classes():
     atk = APGDAttack(n_iter=2, rho=0.75, max_bound=0.5, ce_loss=False)
     with pytest.raises(AttributeError):
         atk.dlr_loss(torch.randn(1, 3), torch.tensor([0]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the attacks batched over images.  Every image of a batch must come out as from its own one-image run
+# (which the goldens above pin to the reference), whatever the other images of the batch do: per-sample norms, masks, early
+# exits, step sizes, bests.
+def _content_noise(image):
+    """N(0,1) noise as a function of the image itself, so that batched and one-image runs draw the same noise per image"""
+    out = []
+    for b in range(image.shape[0]):
+        g = torch.Generator().manual_seed(int(image[b].double().sum().item() * 1e6) % (2 ** 31))
+        out.append(torch.randn(image[b:b + 1].shape, generator=g))
+    return torch.cat(out, dim=0)
+
+
+@pytest.mark.parametrize('name', ['fgsm', 'deepfool', 'apgd_ce', 'apgd_dlr', 'fab'])
+def test_batched_attack_equals_the_one_image_runs(name, gold, monkeypatch):
+    from gen_adversarial_amd.attacks import l2_attacks
+    monkeypatch.setattr(l2_attacks, '_per_image_randn', _content_noise)
+    net = toy_net()
+    images, labels = torch.from_numpy(gold['images']), torch.from_numpy(gold['labels'])
+    # a fourth image that is misclassified from the start (returns success with distortion 0 and must not disturb the others)
+    images = torch.cat([images, images[:1].flip(-1)], dim=0)
+    with torch.no_grad():
+        wrong = (net(images[3:]).argmax(dim=1) + 1) % 6
+    labels = torch.cat([labels, wrong], dim=0)
+    singles = [ATTACKS[name]()(images[i:i + 1].clone(), labels[i:i + 1].clone(), net) for i in range(4)]
+    s, b, a = ATTACKS[name]()(images.clone(), labels.clone(), net)
+    assert s.shape == (4,) and b.shape == (4,) and a.shape == images.shape
+    for i, (s1, b1, a1) in enumerate(singles):
+        assert bool(s[i]) == bool(s1), (name, i)
+        if bool(s1):
+            assert float(b[i]) == pytest.approx(float(b1), rel=1e-5, abs=1e-6), (name, i)
+        np.testing.assert_allclose(a[i:i + 1].detach().numpy(), a1.detach().numpy(), atol=1e-5, err_msg=f'{name} {i}')
+    assert bool(s[3]) and float(b[3]) == 0.0 or name.startswith('apgd')       # APGD has no "already misclassified" exit (:246-322)
+
+
+def test_batched_autoattack_equals_the_one_image_runs(gold, monkeypatch):
+    from gen_adversarial_amd.attacks import l2_attacks
+    monkeypatch.setattr(l2_attacks, '_per_image_randn', _content_noise)
+    net = toy_net()
+    images, labels = torch.from_numpy(gold['images']), torch.from_numpy(gold['labels'])
+
+    def make():
+        aa = AutoAttack()
+        for atk in aa.ce + aa.dlr:
+            atk.__init__(n_iter=10, rho=0.75, max_bound=atk.max_bound, ce_loss=not (atk.criterion == atk.dlr_loss))
+        aa.fab.n_iter = 6
+        return aa
+    singles = [make()(images[i:i + 1].clone(), labels[i:i + 1].clone(), net) for i in range(3)]
+    s, b, a = make()(images.clone(), labels.clone(), net)
+    for i, (s1, b1, a1) in enumerate(singles):
+        assert bool(s[i]) == bool(s1)
+        assert float(b[i]) == pytest.approx(float(b1), rel=1e-5, abs=1e-6)
+        np.testing.assert_allclose(a[i:i + 1].numpy(), a1.numpy(), atol=1e-5)
+
+
+def test_class_gradients_one_pass_per_class_for_the_whole_batch():
+    """the multi-class VJP of DeepFool / FAB: per image the gradients of ITS OWN class list, from one forward"""
+    from gen_adversarial_amd.attacks.l2_attacks import class_gradients
+    net = toy_net()
+    x = torch.rand(3, 3, 16, 16, generator=torch.Generator().manual_seed(2))
+    classes = torch.tensor([[0, 3], [5, 1], [2, 2]])
+    y, g = class_gradients(net, x, classes)
+    assert g.shape == (3, 2, 3, 16, 16)
+    for b in range(3):
+        for j in range(2):
+            xr = x[b:b + 1].clone().requires_grad_(True)
+            (ref,) = torch.autograd.grad(net(xr)[0, classes[b, j]], [xr])
+            np.testing.assert_allclose(g[b, j].numpy(), ref[0].numpy(), atol=1e-6)
+    y2, g2 = class_gradients(net, x)
+    assert g2.shape == (3, 6, 3, 16, 16) and torch.allclose(g2[1, 5], g[1, 0], atol=1e-6)
