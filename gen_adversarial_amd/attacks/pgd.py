@@ -8,15 +8,35 @@ kept busy with B x EoT defender rows per step; B = 1 reproduces the reference's 
 """
 from __future__ import annotations
 
+from contextlib import contextmanager
+
 import torch
+
+
+@contextmanager
+def bpda(net: torch.nn.Module):
+    """Backward Pass Differentiable Approximation (Athalye, Carlini & Wagner 2018) for the attack BASELINE.json names
+    ("PGD-40 + BPDA"; the reference tree has neither): inside the block, gradients through the MLVGM defender
+    wrapped by `net` (directly or inside an EoTWrapper) count the purifier as the identity — forward passes stay exact."""
+    target = getattr(net, 'model', net)
+    if not hasattr(target, 'bpda'):
+        raise TypeError('BPDA needs an MLVGM defender (a purifier in front of a classifier); '
+                        f'{type(target).__name__} has none')
+    old = target.bpda
+    target.bpda = True
+    try:
+        yield net
+    finally:
+        target.bpda = old
 
 
 class PGDLinf:
     batched = True      # `image` may hold several images: each is attacked independently (see test_defense.evaluate_shard)
 
     def __init__(self, eps: float = 8.0 / 255.0, step_size: float = 2.0 / 255.0, steps: int = 40,
-                 random_start: bool = False):
+                 random_start: bool = False, bpda: bool = False):
         self.eps, self.step_size, self.steps, self.random_start = eps, step_size, steps, random_start
+        self.bpda = bpda            # gradients with the purifier counted as the identity (see bpda() above)
 
     @staticmethod
     def step(x_adv: torch.Tensor, x_orig: torch.Tensor, grad: torch.Tensor, eps: float, step_size: float,
@@ -29,6 +49,12 @@ class PGDLinf:
         return nxt
 
     def __call__(self, image: torch.Tensor, gt_label: torch.Tensor, net: torch.nn.Module):
+        if self.bpda:
+            with bpda(net):
+                return self._run(image, gt_label, net)
+        return self._run(image, gt_label, net)
+
+    def _run(self, image: torch.Tensor, gt_label: torch.Tensor, net: torch.nn.Module):
         x_orig = image.detach()
         x_adv = x_orig.clone()
         if self.random_start:

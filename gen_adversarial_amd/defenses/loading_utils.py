@@ -139,6 +139,24 @@ class E4EWeights:
         return self
 
 
+def estimate_latent_avg(decoder_sd: Dict[str, torch.Tensor], gspec, device: str, n_latent: int = 10000, seed: Optional[int] = None) -> torch.Tensor:
+    """pSp.__load_latent_avg for a checkpoint without 'latent_avg' (psp.py:117-125 -> Generator.mean_latent,
+    stylegan2/generator.py:388-395): the mean of the mapping network over `n_latent` N(0,1) latents, [1, style_dim].  The
+    mapping network runs on the HIP engine (PixelNorm + 8 FC layers, engine_stylegan.build_mapping); the draw is torch's device
+    RNG (the reference's estimate is equally a random draw: the two agree statistically, not bit for bit)."""
+    from ..engine import Engine
+    eng = Engine.bare(n_latent, device=device, need_backward=False)
+    z = eng.alloc((n_latent, gspec.style_dim))
+    out = eng.build_mapping(decoder_sd, z)
+    eng.finish()
+    g = None
+    if seed is not None:
+        g = torch.Generator(device=device).manual_seed(seed)
+    z.normal_(generator=g)
+    eng.forward()
+    return out.view(n_latent, gspec.style_dim).double().mean(dim=0, keepdim=True).float()
+
+
 def load_E4EStyleGan(checkpoint_path: str, device: str) -> E4EWeights:
     """src/defenses/loading_utils.py:37-48 + pSp.load_weights (psp.py:39-46,119-125): checkpoint keys 'state_dict' (with
     'encoder.' / 'decoder.' prefixes), 'latent_avg', 'opts'.  Widths and depths are read off the tensors, so reduced test
@@ -172,7 +190,7 @@ def load_E4EStyleGan(checkpoint_path: str, device: str) -> E4EWeights:
             avg = avg.view(1, -1).expand(gspec.n_latent, -1)
         avg = avg.reshape(gspec.n_latent, gspec.style_dim).contiguous()
     elif opts.get('start_from_latent_avg', False):
-        raise NotImplementedError("checkpoint without 'latent_avg': the reference estimates it from 10000 random latents (psp.py:122-125)")
+        avg = estimate_latent_avg(dec, gspec, device).cpu().expand(gspec.n_latent, -1).contiguous()
     else:
         avg = None
     if not opts.get('start_from_latent_avg', False):

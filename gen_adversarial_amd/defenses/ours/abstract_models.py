@@ -61,7 +61,12 @@ class _EngineFn(torch.autograd.Function):
             eng.dpurified.copy_(dpurified)
         if not use_logits and not use_purified:
             return torch.zeros_like(ctx.x), None, None, None
-        eng.backward(from_logits=use_logits, from_purified=use_purified)
+        if getattr(ctx.owner, 'bpda', False):               # BPDA: identity in place of the purifier's Jacobian
+            if not use_logits:
+                return torch.zeros_like(ctx.x), None, None, None
+            eng.backward(identity_purifier=True)
+        else:
+            eng.backward(from_logits=use_logits, from_purified=use_purified)
         return eng.dx.clone(), None, None, None
 
 
@@ -193,6 +198,9 @@ class MLVGMDefenseModel(ABC, _EngineOwner):
         self.postprocess = self.mean is not None
         self.interpolation_alphas = [a * alpha_attenuation for a in interpolation_alphas]
         self.autoencoder = self.load_autoencoder(autoencoder_path, device)
+        # BPDA switch (not in the reference, whose attacks are fully white-box): when True, autograd through this defender
+        # treats the purifier as the identity (Engine.backward(identity_purifier=True)); see attacks.pgd.bpda
+        self.bpda = False
 
     @abstractmethod
     def load_autoencoder(self, model_path: str, device: str):

@@ -344,6 +344,21 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
             for step in reversed(self._bwd_steps[:n_nvae_steps]):
                 step()
         self._bwd_steps = None
+        # BPDA (Athalye et al. 2018; the attack BASELINE.json names beside PGD): the purifier's Jacobian is replaced by the
+        # identity in the backward pass — the cotangent of the classifier's input image goes straight to the defender's input,
+        # summed over the EoT replicas (the adjoint of x.repeat(eot)); blur / noise / purify are all skipped.
+        self.bpda = None
+        pg = self._purified_grad_nhwc
+        if self.need_backward and pg is not None:
+            s2d = int(pg.c == 4 * IMG_LD)
+            hp = pg.h * (2 if s2d else 1)
+            if hp == self.resolution[1]:                    # same size in and out (a face_pool to another size has no identity)
+                b = L.ImageIoDesc()
+                b.x_nchw, b.dy_nhwc, b.dx_nchw = _ptr(self.x_in), _ptr(pg.g), _ptr(self.dx)
+                b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = self.rows, 3, hp, hp, self.rep, 1, IMG_LD, s2d
+                self.bpda = L.Plan()
+                self.bpda.add(b, 'bpda_identity^T')
+                self.bpda.finalize()
         self.ws = self.alloc((WS_FLOATS,)) if not self.dry_run else None
         self.apply_tuning(tune_cache())
 
@@ -487,13 +502,23 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
         else:
             self.fwd.run(self.stream())
 
-    def backward(self, from_logits: bool = True, from_purified: bool = False):
+    def backward(self, from_logits: bool = True, from_purified: bool = False, identity_purifier: bool = False):
         """Backward-to-input of the last forward.  Cotangents are read from `self.dlogits` (rows x classes) when
-        from_logits and from `self.dpurified` (NCHW) when from_purified.  May be called repeatedly per forward."""
+        from_logits and from `self.dpurified` (NCHW) when from_purified.  May be called repeatedly per forward.
+        identity_purifier: BPDA — backward through the classifier only, the purifier (and the pre-processing in front of it)
+        counted as the identity: dx[image] = sum over its EoT replicas of d loss / d purified."""
         if not self.need_backward:
             raise RuntimeError('engine was built without a backward plan')
         if self.dry_run:
             raise RuntimeError('dry-run engine: plans were built for validation only')
+        if identity_purifier:
+            if self.bpda is None:
+                raise RuntimeError('BPDA needs a purifier whose output has the size of its input')
+            if not from_logits or from_purified:
+                raise ValueError('BPDA starts from the logits')
+            self.bwd.run(self.stream(), start=0, end=self.bwd_split)
+            self.bpda.run(self.stream())
+            return
         if self.dpurified is not None and not from_purified:
             self.dpurified.zero_()
         if from_logits:

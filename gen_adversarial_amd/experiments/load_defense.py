@@ -37,6 +37,7 @@ def load(args: Namespace):
         # PGD-Linf eps=8/255 is the attack BASELINE.json names (not in the reference tree); same call protocol,
         # selected with `--attack pgd`
         args.pgd = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40)
+        args.pgd_bpda = PGDLinf(eps=8.0 / 255.0, step_size=2.0 / 255.0, steps=40, bpda=True)     # BASELINE.json configs[3]
         base_classifier = CelebaIdentityClassifier(d_params.classifier_path, args.device)
         hl_instance = NVAEDefenseModel
     elif args.experiment == 'gender':

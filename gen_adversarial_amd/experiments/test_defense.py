@@ -95,7 +95,7 @@ def gather_results(local: torch.Tensor, world: int, device) -> torch.Tensor:
 
 # results.json column of each attack (test_defense.py:267-287 writes 'Clean', 'DeepFool', 'C&W', 'AutoAttack'; 'PGD' is this
 # build's plug-in and has no reference counterpart)
-RESULT_KEYS = {'deepfool': 'DeepFool', 'c&w': 'C&W', 'autoattack': 'AutoAttack', 'pgd': 'PGD'}
+RESULT_KEYS = {'deepfool': 'DeepFool', 'c&w': 'C&W', 'autoattack': 'AutoAttack', 'pgd': 'PGD', 'pgd-bpda': 'PGD-BPDA'}
 
 
 def merge_results(path: str, clean: float, columns: Dict[str, List[float]]):
@@ -181,7 +181,7 @@ def parse_args(argv=None):
     p.add_argument('--defense_type', type=str, choices=['base', 'A-VAE', 'ND-VAE', 'trades', 'ours', 'ablation'])
     p.add_argument('--experiment', type=str, choices=['gender', 'ids', 'cars'])
     p.add_argument('--config', type=str, required=True)
-    p.add_argument('--attack', type=str, choices=['deepfool', 'c&w', 'autoattack', 'pgd'], default=None,
+    p.add_argument('--attack', type=str, choices=['deepfool', 'c&w', 'autoattack', 'pgd', 'pgd-bpda'], default=None,
                    help='If passed, try a specific attack only. Otherwise, try all (the reference\'s three).')
     p.add_argument('--batch_images', type=int, default=1,
                    help='images per defender call for the clean pass and for batched attacks (PGD); 1 = the reference protocol')
@@ -204,6 +204,8 @@ def main():
         a, m = load(a)
         if a.attack == 'pgd':
             a.attacks = {'pgd': a.pgd}
+        elif a.attack == 'pgd-bpda':
+            a.attacks = {'pgd-bpda': getattr(a, 'pgd_bpda', None) or type(a.pgd)(eps=a.pgd.eps, step_size=a.pgd.step_size, steps=a.pgd.steps, bpda=True)}
         elif a.attack is not None:
             a.attacks = {k: v for k, v in a.attacks.items() if k == a.attack}
         return a, m

@@ -258,3 +258,52 @@ def test_batched_deepfool_and_fab_equal_the_one_image_protocol(setup):
     finally:
         model.model.interpolation_alphas[:] = old
         model.model.fixed_noise(None, None)
+
+
+def test_bpda_gradient_is_the_classifier_gradient_at_the_purified_image(setup):
+    """BPDA (north_star "PGD-40 + BPDA"; new code on the reference's protocol): forward exact, backward with the purifier
+    counted as the identity: dx = sum over the EoT replicas of d loss / d purified — checked against the oracle's classifier
+    gradient at the oracle's purified images; and PGD-Linf(bpda=True) runs on it"""
+    from gen_adversarial_amd.attacks.pgd import PGDLinf, bpda
+    args, model, ck, vsd, alphas = setup
+    spec = build_spec(CFG, RES)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, *RES, generator=g)
+    eps = [torch.randn(2 * EOT, 4, gs.res, gs.res, generator=g) for gs in spec.groups]
+    noise = torch.randn(2 * EOT, *RES, generator=g)
+    with torch.no_grad():
+        _, purified = _oracle(setup, x, eps, noise, EOT)
+    pr = purified.clone().requires_grad_(True)
+    logits = D.classifier_call(vsd, build_vgg_spec(100, 16), pr).view(2, EOT, -1).mean(dim=1)
+    loss = torch.nn.functional.cross_entropy(logits, logits.argmax(dim=1).detach(), reduction='sum')
+    (gp,) = torch.autograd.grad(loss, [pr])
+    ref = gp.view(2, EOT, *RES).sum(dim=1)
+
+    model.model.fixed_noise([e.to(DEV) for e in eps], noise.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    with bpda(model):
+        out = model(xd)
+        l2 = torch.nn.functional.cross_entropy(out, out.argmax(dim=1).detach(), reduction='sum')
+        (gd,) = torch.autograd.grad(l2, [xd])
+    assert model.model.bpda is False
+    assert (out.detach().cpu() - logits.detach()).abs().max().item() < 1e-3
+    rel = ((gd.cpu() - ref).norm() / ref.norm()).item()
+    print(f'BPDA gradient vs oracle classifier gradient at the purified image: relL2 {rel:.2e}')
+    assert rel < 2e-2
+    from gradcheck import assert_grad_given_engine_decisions
+    eng = model.model._engine(2 * EOT, EOT)
+
+    def lossfn(p_):
+        lg = D.classifier_call(vsd, build_vgg_spec(100, 16), p_).view(2, EOT, -1).mean(dim=1)
+        return torch.nn.functional.cross_entropy(lg, logits.argmax(dim=1).detach(), reduction='sum')
+    with torch.no_grad():
+        eng_purified = eng.purified.cpu()
+    gfull = eng.acts['purified_nhwc'].g[..., :3].permute(0, 3, 1, 2)
+    assert_grad_given_engine_decisions(eng, lossfn, eng_purified, gfull, 1e-3, 'classifier gradient at the purified image', min_matched=8)
+    assert torch.allclose(gd, gfull.view(2, EOT, *RES).sum(dim=1), atol=1e-6)
+    model.model.fixed_noise(None, None)
+    s, b, adv = PGDLinf(eps=8 / 255, step_size=2 / 255, steps=3, bpda=True)(x.to(DEV), out.argmax(dim=1), model)
+    assert adv.shape == x.shape and float(torch.as_tensor(b).max()) <= 8 / 255 + 1e-6
+    with pytest.raises(TypeError):
+        with bpda(torch.nn.Linear(2, 2)):
+            pass

@@ -300,3 +300,25 @@ def test_e4e_defender_matches_the_reference_purify_golden(precision, tol):
     s_ = both.abs().max().item()
     assert (both - d_logits - eng.dx).abs().max().item() < 1e-4 * s_
     del codes
+
+
+def test_latent_avg_is_estimated_when_the_checkpoint_has_none(tmp_path):
+    """pSp.__load_latent_avg (psp.py:117-125): start_from_latent_avg without a stored 'latent_avg' -> mean of the mapping
+    network over 10000 random latents; compared with the oracle's mapping network on the same draw and, statistically, with
+    an independent draw"""
+    from gen_adversarial_amd.defenses.loading_utils import estimate_latent_avg, load_E4EStyleGan
+    from oracle import stylegan_oracle as S
+    _, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = _small_e4e_defense(dry_run=True, device='cpu')
+    est = estimate_latent_avg(gsd, gspec, DEV, n_latent=4096, seed=3)
+    z = torch.empty(4096, gspec.style_dim, device=DEV).normal_(generator=torch.Generator(device=DEV).manual_seed(3)).cpu()
+    ref = S.mapping_network(gsd, z).double().mean(dim=0, keepdim=True).float()
+    assert est.shape == (1, gspec.style_dim)
+    assert (est.cpu() - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    ck = {'state_dict': {**{'encoder.' + k: v for k, v in esd.items()}, **{'decoder.' + k: v for k, v in gsd.items()}},
+          'opts': {'stylegan_size': gspec.size, 'start_from_latent_avg': True, 'encoder_type': 'Encoder4Editing'}}
+    torch.save(ck, tmp_path / 'e4e_noavg.pt')
+    w = load_E4EStyleGan(str(tmp_path / 'e4e_noavg.pt'), DEV)
+    assert w.latent_avg.shape == (gspec.n_latent, gspec.style_dim)
+    assert torch.equal(w.latent_avg[0], w.latent_avg[-1])                       # one mean latent, repeated over the indices
+    spread = S.mapping_network(gsd, z).std(dim=0).max().item() / 100.0          # standard error of a 10000-sample mean
+    assert (w.latent_avg[0] - ref[0]).abs().max().item() < 6 * spread + 1e-3

@@ -325,3 +325,23 @@ def test_e4e_defense_plans_build_without_a_gpu():
     n_of = {n: d.N for d, n in zip(sh.fwd.descs, sh.fwd.names) if hasattr(d, 'N')}
     assert n_of['e4e.input.conv'] == 2 and n_of['conv1.conv'] == 6 and n_of['resnet.conv1'] == 6
     assert sh.x_in.shape[0] == 2 and sh.dx.shape[0] == 2 and sh.dlogits.shape[0] == 6
+
+
+def test_every_reference_config_is_present_and_parses():
+    """configs/*.yaml are the reference's files, copied as data: 45 files; each `ours_*` config has one alpha
+    per latent index of its experiment (24 NVAE groups / 18 e4e styles / 16 Style-Transformer styles)"""
+    import glob
+    import os
+    import yaml
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'configs')
+    files = sorted(glob.glob(os.path.join(root, '*.yaml')))
+    assert len(files) == 45
+    n_alpha = {'ids': 24, 'gender': 18, 'cars': 16}
+    for f in files:
+        y = yaml.safe_load(open(f))
+        assert 'classifier_path' in y
+        name = os.path.basename(f)
+        if name.startswith('ours_'):
+            exp = name[:-5].split('_')[-1]
+            assert len(y['interpolation_alphas']) == n_alpha[exp], name
+            assert {'autoencoder_path', 'alpha_attenuation', 'initial_noise_eps', 'gaussian_blur_input'} <= set(y)
