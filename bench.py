@@ -56,13 +56,70 @@ def conv_algorithmic_bytes(plan):
     return total
 
 
-def pmc_traffic():
-    """HBM bytes per conv launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)"""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_v3_summary.json')) as f:
-            return float(json.load(f)['conv_kernels']['hbm_bytes_per_launch'])
-    except Exception:
-        return None
+ROCPROF = '/opt/rocm/bin/rocprofv3'
+
+
+def pmc_child(args):
+    """--pmc-child: what the two counter passes profile — ONE forward + backward replay of the chunk plans (the launches
+    `roofline.achieved` is about).  Started by measure_pmc_traffic() under `rocprofv3 --pmc <counter> --kernel-trace`."""
+    eng, _ = build_model('cuda:0', args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
+    eng.x_in.uniform_()
+    for e in eng.eps:
+        e.normal_()
+    eng.forward()
+    eng.dlogits.normal_()
+    eng.backward()
+    torch.cuda.synchronize()
+
+
+def measure_pmc_traffic(args):
+    """HBM bytes per conv launch, measured in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: the TCC has
+    4 counter slots, they cost 3 + 2) over a child process that replays one chunk's forward + backward plan.  Units and gfx950
+    correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KB; FETCH_SIZE reports
+    half of the bytes of wide coalesced reads (doubled here), WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+    Runs BEFORE this process touches the GPU (children of a GPU-initialised process must not be exec'ed on this pool).
+    Returns (bytes per conv launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = ROCPROF if os.path.exists(ROCPROF) else shutil.which('rocprofv3')
+    if exe is None:
+        return None, 'rocprofv3 not found'
+    sums = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix=f'ga_pmc_{counter.lower()}_', dir=os.environ.get('TMPDIR', '/tmp'))
+        cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
+               sys.executable, os.path.abspath(__file__), '--pmc-child', '--chunk-rows', str(args.chunk_rows), '--eot', str(args.eot),
+               '--precision', args.precision] + (['--share-encoder'] if args.share_encoder else [])
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.pmc_timeout, cwd=os.environ.get('TMPDIR', '/tmp'))
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f'{counter} pass timed out after {args.pmc_timeout} s'
+        files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f'{counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}'
+        tot, n = 0.0, 0
+        for f in files:
+            with open(f, newline='') as fh:
+                for row in csv.DictReader(fh):
+                    name = row['Kernel_Name']
+                    if row['Counter_Name'] == counter and 'ga::conv_' in name and 'splitk' not in name:
+                        tot += float(row['Counter_Value'])
+                        n += 1
+        shutil.rmtree(d, ignore_errors=True)
+        if n == 0:
+            return None, f'{counter} pass saw no conv launch'
+        sums[counter] = (tot, n)
+    fetch, nf = sums['FETCH_SIZE']
+    write, nw = sums['WRITE_SIZE']
+    per_launch = 2.0 * fetch * 1024.0 / nf + write * 1024.0 / nw
+    return per_launch, (f'measured in this run before the timed region: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, '
+                        f'--kernel-trace only) over one forward + backward replay of a {args.chunk_rows}-row chunk plan in a child process; '
+                        f'{nf} conv launches; bytes = 2 x FETCH_SIZE KB (gfx950 counts half of wide coalesced reads) + WRITE_SIZE KB')
 
 
 def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False, store=None):
@@ -193,6 +250,128 @@ def cpu_baseline(model, rows, rep, check=None):
                       f'{dt:.1f} s of oracle (PyTorch CPU fp32) time, dX only'}
 
 
+def _time_steps(fn, n, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+def secondary_measurements(out, args, device, model, store, x, labels):
+    """Driver-visible figures beside the headline (never `value`): the exact-fp32 arithmetic at the same configuration, the
+    reference's own protocol (ONE image x EoT 32 per defender call: src/experiments/test_defense.py:116,60) eager and as HIP
+    graphs, and BASELINE.json configs[2] (e4e + StyleGAN2-1024 + ResNet-50, 256 px, eps 4.0) with its own roofline block."""
+    sec = out.setdefault('secondary', {})
+    # ---- exact fp32 (v_mfma_f32_32x32x2_f32) at the headline configuration: two chunks per step on one stream
+    try:
+        log('secondary: fp32 precision ...')
+        e32, _ = build_model(device, args.chunk_rows, args.eot, seed=0, precision='fp32', share_encoder=False)
+        n_img = 2 * args.chunk_rows // args.eot
+        st = AttackStep([e32], [torch.cuda.Stream(device=device)], labels[:n_img].clone(), x[:n_img].clone())
+        t = _time_steps(st, 2, warm=1)
+        f_ms, fc_ms, fn = e32.fwd.time(e32.stream(), iters=1, per_conv=True)
+        b_ms, bc_ms, bn = e32.bwd.time(e32.stream(), iters=1, per_conv=True)
+        fl = conv_algorithmic_flops(e32.fwd) + conv_algorithmic_flops(e32.bwd)
+        sec['fp32_precision'] = {'rows_per_s': 2 * args.chunk_rows / t, 'ms_per_step': t * 1e3, 'dtype': 'f32 (exact f32 MFMA)',
+                                 'what': f'{n_img} images x EoT {args.eot} per step ({args.chunk_rows}-row chunks, 1 stream), same workload as the headline',
+                                 'roofline': {'bound': 'mfma', 'achieved': fl / ((fc_ms + bc_ms) / 1e3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                                              'unit': 'TFLOP/s', 'frac': fl / ((fc_ms + bc_ms) / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}
+        del st, e32
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        sec['fp32_precision'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
+    # ---- the reference protocol: one image x EoT 32 per call
+    try:
+        log('secondary: reference protocol (1 image x EoT 32) ...')
+        e1, _ = build_model(device, args.eot, args.eot, seed=0, precision=args.precision, share_encoder=False, store=store)
+        st = AttackStep([e1], [torch.cuda.Stream(device=device)], labels[:1].clone(), x[:1].clone())
+        t_eager = _time_steps(st, 20, warm=3)
+        with torch.cuda.stream(st.streams[0]):
+            e1.enable_graphs()
+        t_graph = _time_steps(st, 20, warm=3)
+        e1.disable_graphs()
+        sec['reference_protocol_1_image'] = {'rows_per_s_eager': args.eot / t_eager, 'ms_per_step_eager': t_eager * 1e3,
+                                             'rows_per_s_hip_graph': args.eot / t_graph, 'ms_per_step_hip_graph': t_graph * 1e3,
+                                             'launches_per_step': len(e1.fwd) + len(e1.bwd),
+                                             'what': f'1 image x EoT {args.eot} = {args.eot} defender rows per attack step (the batch size the reference\'s '
+                                                     'attacks use); literal x.repeat(eot) path'}
+        del st, e1
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        sec['reference_protocol_1_image'] = {'rows_per_s_eager': None, 'what': f'failed: {ex}'}
+    # ---- configs[2]: e4e + StyleGAN2-1024 defender, ResNet-50, 256 px, 64 rows per step, input noise eps 4.0
+    try:
+        log('secondary: configs[2] e4e + StyleGAN2 defender ...')
+        sec['configs2_e4e_defender'] = e4e_defender_measurement(args, device)
+    except Exception as ex:
+        sec['configs2_e4e_defender'] = {'rows_per_s': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
+    torch.cuda.empty_cache()
+
+
+def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
+    """BASELINE.json configs[2] (configs/ours_cosine_noise_gender.yaml: 18 cosine alphas, initial_noise_eps 4.0): IR-SE50 e4e
+    encoder on 256 px -> 18 x 512 latents mixed with mapped noise -> StyleGAN2 at 1024 px -> face_pool 256 -> ResNet-50, forward
+    + backward-to-input (one PGD-Linf iteration), 64 defender rows per step as two 32-row plan runs (1 image x EoT 32 each; a
+    32-row plan holds ~100 GB of activations).  Random weights, synthetic images."""
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    with open(os.path.join(ROOT, 'configs', 'ours_cosine_noise_gender.yaml')) as f:
+        y = yaml.safe_load(f)
+    alphas = [a * y['alpha_attenuation'] for a in y['interpolation_alphas']]
+    espec, esd = build_e4e_spec(1024), init_e4e_state_dict(1024, 1, 0)
+    gspec = build_stylegan_spec(1024)
+    gsd = init_stylegan_state_dict(gspec, 1)
+    cspec, csd = build_resnet_spec(2), init_resnet_state_dict(2, 1, 2)
+    avg = 0.1 * torch.randn(18, 512, generator=torch.Generator().manual_seed(5))
+    eng = Engine.bare(chunk, device=device, precision=args.precision, rep=eot, resolution=(3, 256, 256), alphas=alphas,
+                      noise_eps=float(y['initial_noise_eps']))
+    eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=256)
+    n_img = rows // eot
+    g = torch.Generator(device=device).manual_seed(7)
+    x = torch.rand(n_img, 3, 256, 256, device=device, generator=g)
+    x_adv = x.clone()
+    labels = torch.zeros(n_img, dtype=torch.long, device=device)
+    per = chunk // eot
+
+    def step():
+        for c in range(n_img // per):
+            lo, hi = c * per, (c + 1) * per
+            eng.x_in.copy_(x_adv[lo:hi])
+            eng.eps[0].normal_()
+            eng.noise.normal_()
+            eng.noise_coef.copy_(eng.noise_eps / eng.noise.flatten(1).norm(dim=1))
+            eng.forward()
+            lg = eng.logits.view(-1, eot, eng.logits.shape[-1]).mean(dim=1)
+            p = torch.softmax(lg, dim=1)
+            p[torch.arange(p.shape[0], device=p.device), labels[lo:hi]] -= 1.0
+            eng.dlogits.view(-1, eot, p.shape[-1]).copy_((p / eot).unsqueeze(1).expand(-1, eot, -1))
+            eng.backward()
+            nxt = x_adv[lo:hi] + (2.0 / 255.0) * eng.dx.sign()
+            x_adv[lo:hi] = torch.min(torch.max(nxt, x[lo:hi] - 8.0 / 255.0), x[lo:hi] + 8.0 / 255.0).clamp_(0.0, 1.0)
+    t = _time_steps(step, 3, warm=1)
+    s = eng.stream()
+    f_ms, fc_ms, fn = eng.fwd.time(s, iters=1, per_conv=True)
+    b_ms, bc_ms, bn = eng.bwd.time(s, iters=1, per_conv=True)
+    flops = conv_algorithmic_flops(eng.fwd) + conv_algorithmic_flops(eng.bwd)
+    achieved = flops / ((fc_ms + bc_ms) / 1e3) / 1e12
+    peak = PEAK_BF16X3_TFLOPS if args.precision == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
+    res = {'rows_per_s': rows / t, 'ms_per_step': t * 1e3, 'rows_per_step': rows, 'chunk_rows': chunk,
+           'what': f'configs[2]: e4e (IR-SE50 @256 px) + StyleGAN2-1024 + face_pool + ResNet-50, {n_img} images x EoT {eot} = {rows} defender rows per '
+                   f'PGD step (forward + input gradient), initial_noise_eps {y["initial_noise_eps"]}, alphas ours_cosine_noise_gender.yaml, '
+                   f'{len(eng.fwd)} + {len(eng.bwd)} launches per {chunk}-row plan, {eng.bytes / 1e9:.0f} GB of activations + weights',
+           'roofline': {'bound': 'mfma', 'kernel': 'ga::conv_* (implicit-GEMM conv family)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': achieved / peak, 'traffic': None, 'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                        'algorithmic_gflop_per_chunk': flops / 1e9, 'conv_ms_per_chunk': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
+    del eng
+    return res
+
+
 def log(msg):
     print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
 
@@ -268,12 +447,19 @@ def main():
                     help='collective backend; gloo (CPU tensors) only to rehearse N>1 on a box with fewer GPUs than ranks')
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default='bf16x3',
                     help="dense contractions: 'bf16x3' = 3 bf16 MFMAs per product (logits within ~2e-5 of fp32), 'fp32' = exact f32 MFMA")
+    ap.add_argument('--pmc-child', action='store_true', help='internal: the process the PMC passes profile (see measure_pmc_traffic)')
+    ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc passes (roofline.traffic = null)')
+    ap.add_argument('--pmc-timeout', type=int, default=240)
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip every secondary measurement (rows256, shared encoder, fp32, reference protocol, e4e defender)')
     ap.add_argument('--stub-engine', action='store_true',
                     help='TEST REHEARSAL ONLY: CPU stand-in engines (needs --backend gloo); exercises launcher / collectives / JSON')
     args = ap.parse_args()
     if args.stub_engine and args.backend != 'gloo':
         raise SystemExit('--stub-engine is a CPU rehearsal of the multi-rank plumbing: use it with --backend gloo')
 
+    if args.pmc_child:
+        return pmc_child(args)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         return launch_ranks(args, sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -282,6 +468,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N starts them '
                          'itself; under torch.distributed.run pass the same N)')
+    pmc_bytes, pmc_note = None, 'skipped'
+    if rank == 0 and world == 1 and not args.no_pmc and not args.stub_engine:
+        log('PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one chunk replay in a child process) ...')
+        pmc_bytes, pmc_note = measure_pmc_traffic(args)           # before this process initialises the GPU
+        log(f'PMC: {pmc_bytes} bytes per conv launch ({pmc_note[:80]})')
+    if args.no_secondary:
+        args.no_rows256 = args.no_shared_variant = True
     if args.stub_engine:
         device = 'cpu'
     else:
@@ -395,10 +588,8 @@ def main():
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
                          'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_traffic(),
-                         'traffic_note': 'HBM bytes per conv launch = 2*FETCH_SIZE + WRITE_SIZE from the separate PMC passes '
-                                         'summarised in profiles/r01_pmc_v3_summary.json (same 512-row plans); algorithmic bytes '
-                                         'per launch beside it',
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_bytes,
+                         'traffic_note': 'HBM bytes per conv launch: ' + pmc_note + '; algorithmic bytes per launch beside it',
                          'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                          'peak_note': ('dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-class product; achieved counts '
                                        'algorithmic (1x) flops' if args.precision == 'bf16x3' else 'fp32 MFMA peak'),
@@ -460,6 +651,13 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as ex:
                 out['config']['shared_encoder_variant'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
+        if world == 1 and not args.no_secondary:
+            # the headline engines are no longer needed: free their 134 GB before the other secondary measurements
+            step = None
+            engines.clear()
+            eng = None
+            torch.cuda.empty_cache()
+            secondary_measurements(out, args, device, model, store, x, labels)
         if not args.no_cpu_baseline and world == 1:
             try:
                 log('cpu baseline (oracle on host cores) ...')

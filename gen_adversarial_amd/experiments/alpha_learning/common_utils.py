@@ -52,14 +52,19 @@ class AlphaEvaluator:
         self.images, self.labels = images.to(device), labels.to(device)
 
     @torch.no_grad()
-    def objective_function(self, alphas: Sequence[float]) -> float:
+    def per_image_verdicts(self, alphas: Sequence[float]) -> torch.Tensor:
+        """the (N,) bool tensor the objective averages: EoT-mean prediction == label, per image of the adversarial set"""
         alphas = alphas.cpu().tolist() if isinstance(alphas, torch.Tensor) else list(alphas)
         self.defense_model.model.interpolation_alphas = [a * self.alpha_attenuation for a in alphas]
         hits = []
         for i in range(0, self.images.shape[0], self.batch_images):
             x, y = self.images[i:i + self.batch_images], self.labels[i:i + self.batch_images]
             hits.append(torch.eq(self.defense_model(x).argmax(dim=1), y))
-        return torch.mean(torch.cat(hits).to(torch.float32)).item()
+        return torch.cat(hits)
+
+    @torch.no_grad()
+    def objective_function(self, alphas: Sequence[float]) -> float:
+        return torch.mean(self.per_image_verdicts(alphas).to(torch.float32)).item()
 
 
 @torch.no_grad()

@@ -307,3 +307,69 @@ def test_bpda_gradient_is_the_classifier_gradient_at_the_purified_image(setup):
     with pytest.raises(TypeError):
         with bpda(torch.nn.Linear(2, 2)):
             pass
+
+
+def test_alpha_objective_verdicts_equal_the_oracles_under_fixed_noise(setup):
+    """SURVEY.md §8 row f2 (AlphaEvaluator.objective_function, src/experiments/alpha_learning/common_utils.py:81-103): with the
+    latent noise fixed, every image's verdict (EoT-mean prediction == label) and the accuracy equal the oracle's"""
+    from gen_adversarial_amd.experiments.alpha_learning.common_utils import AlphaEvaluator
+    args, model, ck, vsd, _ = setup
+    cpath = yaml.safe_load(open(args.config))
+    spec = build_spec(CFG, RES)
+    eot, bi, n = 2, 2, 6
+    g = torch.Generator().manual_seed(11)
+    imgs = torch.rand(n, *RES, generator=g)
+    eps = [torch.randn(bi * eot, 4, gs.res, gs.res, generator=g) for gs in spec.groups]
+    cand = torch.rand(len(spec.groups), generator=g)
+    alphas = [float(a) * 0.7 for a in cand]
+    sd = ck['state_dict_temp=0.6']
+    vspec = build_vgg_spec(100, 16)
+    mean_logits = []
+    for i in range(0, n, bi):
+        x = imgs[i:i + bi].repeat_interleave(eot, dim=0)
+        lg, _ = D.nvae_defender(sd, spec, vsd, vspec, x, alphas, eps, torch.zeros_like(x), 0.0)
+        mean_logits.append(lg.view(bi, eot, -1).mean(dim=1))
+    mean_logits = torch.cat(mean_logits)
+    labels = mean_logits.argmax(dim=1).clone()
+    labels[::2] = (labels[::2] + 1) % 100                      # half of the set "stays fooled"
+    ev_args = Namespace(classifier_type='vgg-11', classifier_path=cpath['classifier_path'], autoencoder_path=cpath['autoencoder_path'],
+                        initial_alphas=[0.] * len(spec.groups), eot_steps=eot)
+    ev = AlphaEvaluator(ev_args, DEV, images=imgs, labels=labels, batch_images=bi)
+    ev.defense_model.model.fixed_noise([e.to(DEV) for e in eps], None)
+    hits = ev.per_image_verdicts(cand)
+    ref = mean_logits.argmax(dim=1) == labels
+    top2 = mean_logits.topk(2, dim=1).values
+    assert (top2[:, 0] - top2[:, 1]).min().item() > 1e-3          # no verdict sits on a tie: the comparison is exact
+    assert hits.cpu().tolist() == ref.tolist()
+    assert ev.objective_function(cand) == pytest.approx(ref.float().mean().item())
+
+
+def test_noise_ablation_with_injected_noise_matches_the_oracle(setup, tmp_path):
+    """SURVEY.md §8 row f4 (GaussianNoiseDefenseModel, src/defenses/ablations/models.py:13-39): purified image and logits with
+    the N(0,1) draw injected, against MLVGMDefenseModel.add_gaussian_noise's restatement + the classifier oracle"""
+    args, model, ck, vsd, _ = setup
+    cpath = yaml.safe_load(open(args.config))
+    with open(tmp_path / 'noise.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': cpath['classifier_path'], 'type': 'noise'}, f)
+    eot = 3
+    a, m = load(Namespace(config=str(tmp_path / 'noise.yaml'), experiment='ids', defense_type='ablation', eot_steps=eot, device=DEV))
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, *RES, generator=g)
+    noise = torch.randn(2 * eot, *RES, generator=g)
+    xr = x.clone().requires_grad_(True)
+    noisy = D.add_gaussian_noise(xr.repeat_interleave(eot, dim=0), noise, 2.0)
+    ref = D.classifier_call(vsd, build_vgg_spec(100, 16), noisy).view(2, eot, -1).mean(dim=1)
+    m.model.fixed_noise(None, noise.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    out = m(xd)
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 2e-4
+    eng = m.model._engine(2 * eot, eot)
+    assert (eng.input_image_nchw().cpu() - noisy.detach()).abs().max().item() < 1e-5
+    (gd,) = torch.autograd.grad(out[:, 3].sum(), [xd])
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(
+        eng, lambda t: D.classifier_call(vsd, build_vgg_spec(100, 16), D.add_gaussian_noise(t.repeat_interleave(eot, dim=0), noise, 2.0))
+        .view(2, eot, -1).mean(dim=1)[:, 3].sum(), x, gd, 1e-3, 'noise ablation input gradient', min_matched=8)
+    m.model.fixed_noise(None, None)
+    p = m.get_purified(x[:1].to(DEV))
+    assert abs((p.cpu() - x[:1]).flatten(1).norm(dim=1).item() - 2.0) < 0.2
