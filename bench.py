@@ -250,6 +250,13 @@ def cpu_baseline(model, rows, rep, check=None):
                       f'{dt:.1f} s of oracle (PyTorch CPU fp32) time, dX only'}
 
 
+def free_gpu_memory():
+    """engines hold reference cycles (activation records <-> engine): collect them before returning their HBM"""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def _time_steps(fn, n, warm=2):
     for _ in range(warm):
         fn()
@@ -281,7 +288,7 @@ def secondary_measurements(out, args, device, model, store, x, labels):
                                  'roofline': {'bound': 'mfma', 'achieved': fl / ((fc_ms + bc_ms) / 1e3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                               'unit': 'TFLOP/s', 'frac': fl / ((fc_ms + bc_ms) / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}
         del st, e32
-        torch.cuda.empty_cache()
+        free_gpu_memory()
     except Exception as ex:
         sec['fp32_precision'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
     # ---- the reference protocol: one image x EoT 32 per call
@@ -300,7 +307,7 @@ def secondary_measurements(out, args, device, model, store, x, labels):
                                              'what': f'1 image x EoT {args.eot} = {args.eot} defender rows per attack step (the batch size the reference\'s '
                                                      'attacks use); literal x.repeat(eot) path'}
         del st, e1
-        torch.cuda.empty_cache()
+        free_gpu_memory()
     except Exception as ex:
         sec['reference_protocol_1_image'] = {'rows_per_s_eager': None, 'what': f'failed: {ex}'}
     # ---- configs[2]: e4e + StyleGAN2-1024 defender, ResNet-50, 256 px, 64 rows per step, input noise eps 4.0
@@ -309,7 +316,7 @@ def secondary_measurements(out, args, device, model, store, x, labels):
         sec['configs2_e4e_defender'] = e4e_defender_measurement(args, device)
     except Exception as ex:
         sec['configs2_e4e_defender'] = {'rows_per_s': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
-    torch.cuda.empty_cache()
+    free_gpu_memory()
 
 
 def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
@@ -632,7 +639,7 @@ def main():
                 step = None
                 engines.clear()
                 del eng
-                torch.cuda.empty_cache()
+                free_gpu_memory()
                 es = build_model(device, args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=True, store=store)[0]
                 eng_s = [es] + [Engine_clone(es, model, device, args) for _ in range(n_eng - 1)]
                 imgs = n_chunk_s * args.chunk_rows // args.eot
@@ -648,7 +655,7 @@ def main():
                     'rows_per_s': n_chunk_s * args.chunk_rows / ts,
                     'what': f'{imgs} images x EoT {args.eot} per step, encoder once per image (exact without input noise); API default'}
                 del st, eng_s, es
-                torch.cuda.empty_cache()
+                free_gpu_memory()
             except Exception as ex:
                 out['config']['shared_encoder_variant'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
         if world == 1 and not args.no_secondary:
@@ -656,7 +663,7 @@ def main():
             step = None
             engines.clear()
             eng = None
-            torch.cuda.empty_cache()
+            free_gpu_memory()
             secondary_measurements(out, args, device, model, store, x, labels)
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -641,6 +641,7 @@ __global__ void __launch_bounds__(256) pool_denorm_kernel(const ga_pool_denorm_d
                     acc += ld4(d.x + (((size_t)n * d.H * k + (h * k + a)) * Wi + (w * k + b)) * 4);
             float* o = d.y + ((((size_t)n * (d.H >> 1) + (h >> 1)) * (d.W >> 1) + (w >> 1)) * 4 + ((h & 1) * 2 + (w & 1))) * d.ld;
             floatx4 v = acc * inv + 0.5f;
+            if (d.band > 0 && (h < d.band || h >= d.H - d.band)) v = floatx4{0.f, 0.f, 0.f, 0.f};      // image set to -1: 0.5 * -1 + 0.5
             v[3] = 0.f;
             *reinterpret_cast<floatx4*>(o) = v;
             for (int z = 4; z < d.ld; z += 4) *reinterpret_cast<floatx4*>(o + z) = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -658,6 +659,7 @@ __global__ void __launch_bounds__(256) pool_denorm_kernel(const ga_pool_denorm_d
                 v[0] += d.dy_nchw[o]; v[1] += d.dy_nchw[o + hw]; v[2] += d.dy_nchw[o + 2 * hw];
             }
             v *= inv;
+            if (d.band > 0 && (h < d.band || h >= d.H - d.band)) v = floatx4{0.f, 0.f, 0.f, 0.f};
             v[3] = 0.f;
             *reinterpret_cast<floatx4*>(d.dx + i * 4) = v;
         }

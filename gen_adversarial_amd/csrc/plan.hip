@@ -29,6 +29,9 @@ static int run_one(const ga_op& op, void* stream) {
         case GA_OP_PIXELNORM:    return ga_pixelnorm(op.u.pn.x, op.u.pn.y, op.u.pn.rows, op.u.pn.C, stream);
         case GA_OP_LATENT_MIX:   return ga_latent_mix(&op.u.lm, stream);
         case GA_OP_POOL_DENORM:  return ga_pool_denorm(&op.u.pd, stream);
+        case GA_OP_ATTN:         return ga_attn(&op.u.at, stream);
+        case GA_OP_LAYERNORM:    return ga_layernorm(&op.u.ln, stream);
+        case GA_OP_RESIZE2_CROP: return ga_resize2_crop(&op.u.rc, stream);
         case GA_OP_AXPBY:        return ga_axpby(op.u.ax.x, op.u.ax.y, op.u.ax.n, op.u.ax.alpha, op.u.ax.beta, stream);
         default:                 return GA_E_UNSUPPORTED;
     }

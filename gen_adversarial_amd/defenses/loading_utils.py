@@ -198,4 +198,54 @@ def load_E4EStyleGan(checkpoint_path: str, device: str) -> E4EWeights:
     return E4EWeights(enc, espec, dec, gspec, avg, opts)
 
 
-load_TranStyleGan = _next('load_TranStyleGan')
+@dataclass
+class TransWeights:
+    """what StyleTransformer holds for the defender (StyleGan_Trans/models/style_transformer.py:16-92): encoder / decoder state
+    dicts (the 'encoder.module.' / 'decoder.module.' prefixes stripped), latent_avg, the training options"""
+    encoder_sd: Dict[str, torch.Tensor]
+    encoder_spec: object
+    decoder_sd: Dict[str, torch.Tensor]
+    decoder_spec: object
+    latent_avg: Optional[torch.Tensor]
+    opts: dict
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+
+def load_TranStyleGan(checkpoint_path: str, device: str) -> TransWeights:
+    """src/defenses/loading_utils.py:69-81 + StyleTransformer.load_weights (style_transformer.py:30-37,84-91): checkpoint keys
+    'state_dict' ('encoder.module.*', 'decoder.module.*'), 'latent_avg', 'opts' (output_size, start_from_latent_avg, learn_in_w).
+    Widths and depths are read off the tensors, so reduced test checkpoints load too."""
+    from ..stylegan_spec import build_stylegan_spec
+    from ..trans_spec import build_trans_spec
+    ckpt = _torch_load(checkpoint_path)
+    opts = dict(ckpt['opts'])
+    sd = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    enc = {k[len('encoder.module.'):]: v for k, v in sd.items() if k.startswith('encoder.module.')}
+    dec = {k[len('decoder.module.'):]: v for k, v in sd.items() if k.startswith('decoder.module.')}
+    if not enc or not dec:
+        raise KeyError("a Style-Transformer checkpoint holds 'encoder.module.*' and 'decoder.module.*' (style_transformer.py:34-35)")
+    if opts.get('learn_in_w', False):
+        raise NotImplementedError('learn_in_w checkpoints (one shared latent) are not what the cars defender loads')
+    size = int(opts['output_size'])
+    depths = []
+    i = 0
+    while f'body.{i}.res_layer.1.weight' in enc:
+        depths.append(enc[f'body.{i}.res_layer.1.weight'].shape[0])
+        i += 1
+    units = tuple(depths.count(d) for d in sorted(set(depths)))
+    tspec = build_trans_spec(64 // enc['input_layer.0.weight'].shape[0], units)
+    if enc['z'].shape[1:] != (tspec.n_query, tspec.d_model):
+        raise ValueError(f"encoder.z has shape {tuple(enc['z'].shape)}, expected (1, {tspec.n_query}, {tspec.d_model})")
+    c4 = dec['conv1.conv.weight'].shape[1]
+    gspec = build_stylegan_spec(size, 2, 512 // c4, dec['conv1.conv.modulation.weight'].shape[1])
+    avg = None
+    if opts.get('start_from_latent_avg', False) and 'latent_avg' in ckpt:
+        avg = ckpt['latent_avg'].float()
+        avg = avg.view(1, -1).expand(tspec.n_query, -1) if avg.dim() == 1 else avg
+        avg = avg.reshape(-1, tspec.d_model)[:tspec.n_query].contiguous()
+    return TransWeights(enc, tspec, dec, gspec, avg, opts)

@@ -107,6 +107,8 @@ class _EngineOwner:
                 e.copy_(eps[i])
             else:
                 e.normal_()
+                if getattr(eng, 'eps_std', 1.0) != 1.0:      # TransStyleGanDefenseModel draws N(0, 0.8) (models.py:331)
+                    e.mul_(eng.eps_std)
         if eng.noise is not None:                            # abstract_models.py:132-138
             if inp is not None:
                 eng.noise.copy_(inp)

@@ -31,9 +31,10 @@ from .engine_classifiers import ClassifierBuilder
 from .engine_e4e import E4EBuilder
 from .engine_nvae import NvaeBuilder
 from .engine_stylegan import StyleGanBuilder
+from .engine_trans import TransBuilder
 
 
-class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder):
+class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransBuilder):
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,

@@ -20,38 +20,8 @@ class E4EBuilder:
         es, R = self.vspec, self.rows
         if self.image_s2d:
             raise NotImplementedError
-        inp = self.devd('e4e.input', lambda: F.fold_e4e_input(esd, IMG_LD))
-        t0 = Act(self, R, img.h, img.w, es.base, 'e4e.input.conv')
-        nrm, nrm_b = {}, {}
-        if normalize:
-            c = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
-            nrm = dict(pro_scale=c['two'], pro_shift=c['mone'])
-            nrm_b = dict(dact_x=img.t, dact_scale=c['two'], dact_shift=c['mone'], dact_act=L.GA_ACT_NONE)
-        self.conv(self.fwd, 'e4e.input.conv', img.t, inp['w'], t0.t, bias=inp['b'], K=3, pad=1, **nrm)
-        x = Act(self, R, img.h, img.w, es.base, 'e4e.input')
-        pr = L.PreluDesc()
-        pr.x, pr.slope, pr.y, pr.rows, pr.C, pr.backward = _ptr(t0.t), _ptr(inp['slope']), _ptr(x.t), R * img.h * img.w, es.base, 0
-        self.fwd.add(pr, 'e4e.input.prelu')
-        x_in = x
-
-        def bwd_input():
-            b = L.PreluDesc()
-            b.x, b.slope, b.dy, b.dx, b.rows, b.C, b.backward = (_ptr(t0.t), _ptr(inp['slope']), _ptr(x_in.g), _ptr(t0.g),
-                                                                 R * img.h * img.w, es.base, 1)
-            self.bwd.add(b, 'e4e.input.prelu^T')
-            t0.g_written = True
-            self.grad_conv('e4e.input.conv^T', t0.g, inp['w_bwd'], img, K=3, pad=1, **nrm_b)
-        self._bwd_steps.append(bwd_input)
-
-        feats = {}
-        for i, u in enumerate(es.units):
-            x = self._ir_se_unit(esd, u, x)
-            if i in es.taps:
-                feats[es.taps.index(i)] = x
-        c1, c2, c3 = feats[0], feats[1], feats[2]
-        p2 = self._fpn_level(esd, 'latlayer1', c3, c2)
-        p1 = self._fpn_level(esd, 'latlayer2', p2, c1)
-        src = (c3, p2, p1)
+        x = self._e4e_input_layer(esd, es, img, normalize)
+        src = self._e4e_body_fpn(esd, es, x)
 
         D, cnt = es.style_dim, es.style_count
         out = self.alloc((R, cnt * D))
@@ -67,6 +37,45 @@ class E4EBuilder:
             self._style_head(esd, j, src[es.style_src[j]], out, dout, g0)
         self._bwd_steps.append(bwd_w0)
         return out
+
+    def _e4e_body_fpn(self, esd, es, x: Act):
+        """the 24 IR-SE units and the FPN (encoder.py:113-128; the Style-Transformer's GradualStyleEncoder shares them,
+        style_transformer_encoders.py:59-73): returns (c3, p2, p1)"""
+        feats = {}
+        for i, u in enumerate(es.units):
+            x = self._ir_se_unit(esd, u, x)
+            if i in es.taps:
+                feats[es.taps.index(i)] = x
+        c1, c2, c3 = feats[0], feats[1], feats[2]
+        p2 = self._fpn_level(esd, 'latlayer1', c3, c2)
+        p1 = self._fpn_level(esd, 'latlayer2', p2, c1)
+        return c3, p2, p1
+
+    def _e4e_input_layer(self, esd, es, img: Act, normalize: bool) -> Act:
+        """input conv + BN + PReLU (encoder.py:70-74), optionally with Normalize(0.5, 0.5) as the conv's prologue affine"""
+        R = self.rows
+        inp = self.devd('e4e.input', lambda: F.fold_e4e_input(esd, IMG_LD))
+        t0 = Act(self, R, img.h, img.w, es.base, 'e4e.input.conv')
+        nrm, nrm_b = {}, {}
+        if normalize:
+            c = self.devd('norm05', lambda: {'two': torch.full((IMG_LD,), 2.0), 'mone': torch.full((IMG_LD,), -1.0)})
+            nrm = dict(pro_scale=c['two'], pro_shift=c['mone'])
+            nrm_b = dict(dact_x=img.t, dact_scale=c['two'], dact_shift=c['mone'], dact_act=L.GA_ACT_NONE)
+        self.conv(self.fwd, 'e4e.input.conv', img.t, inp['w'], t0.t, bias=inp['b'], K=3, pad=1, **nrm)
+        x = Act(self, R, img.h, img.w, es.base, 'e4e.input')
+        pr = L.PreluDesc()
+        pr.x, pr.slope, pr.y, pr.rows, pr.C, pr.backward = _ptr(t0.t), _ptr(inp['slope']), _ptr(x.t), R * img.h * img.w, es.base, 0
+        self.fwd.add(pr, 'e4e.input.prelu')
+
+        def bwd_input():
+            b = L.PreluDesc()
+            b.x, b.slope, b.dy, b.dx, b.rows, b.C, b.backward = (_ptr(t0.t), _ptr(inp['slope']), _ptr(x.g), _ptr(t0.g),
+                                                                 R * img.h * img.w, es.base, 1)
+            self.bwd.add(b, 'e4e.input.prelu^T')
+            t0.g_written = True
+            self.grad_conv('e4e.input.conv^T', t0.g, inp['w_bwd'], img, K=3, pad=1, **nrm_b)
+        self._bwd_steps.append(bwd_input)
+        return x
 
     def _ir_se_unit(self, esd, u, x: Act) -> Act:
         """bottleneck_IR_SE (encoding/helpers.py:97-119): shortcut(x) + SE(BN(conv3x3_s(PReLU(conv3x3(BN(x))))))"""

@@ -35,9 +35,10 @@ class LatentSlice:
     written-flag (several layers read the same index: generator.py:452-461)"""
 
     def __init__(self, latent: Act, j: int, dim: int):
-        self.n, self.c, self.ld = latent.n, dim, latent.c
-        self.t = latent.t.view(latent.n, 1, 1, latent.c)[..., j * dim:(j + 1) * dim]
-        self.g = latent.g.view(latent.n, 1, 1, latent.c)[..., j * dim:(j + 1) * dim]
+        ld = getattr(latent, 'ld', latent.c)             # pitch of the code tensor (wider than latent.c for a latent prefix)
+        self.n, self.c, self.ld = latent.n, dim, ld
+        self.t = latent.t.view(latent.n, 1, 1, ld)[..., j * dim:(j + 1) * dim]
+        self.g = latent.g.view(latent.n, 1, 1, ld)[..., j * dim:(j + 1) * dim]
         self.g_written = False
 
 

@@ -443,3 +443,40 @@ def fold_mapping(sd: SD, n_mlp: int, lr_mul: float) -> dict:
         out[f'w{k}'] = f32(w * (lr_mul / w.shape[1] ** 0.5))
         out[f'b{k}'] = f32(sd[f'style.{k}.bias'].double() * lr_mul)
     return out
+
+
+def fold_trans_layer(sd: SD, name: str) -> dict:
+    """TransformerDecoderLayer (StyleGan_Trans/models/transformer.py:17-100): nn.MultiheadAttention's packed in_proj split into
+    what each GEMM needs — self-attention projects q, k, v of the SAME tokens in one GEMM ([3d, d]); cross-attention projects the
+    queries ([d, d]) and the memory tokens (k and v together, [2d, d]) separately — plus out_proj, the FFN and the LayerNorm
+    affine parameters; every matrix also transposed for the backward-to-input GEMMs."""
+    out = {}
+    d = sd[f'{name}.self_attn.out_proj.weight'].shape[0]
+
+    def lin(key, w, b):
+        w = w.double()
+        out[f'{key}_w'], out[f'{key}_w_bwd'], out[f'{key}_b'] = f32(w), f32(w.t().contiguous()), f32(b)
+    lin('sa_qkv', sd[f'{name}.self_attn.in_proj_weight'], sd[f'{name}.self_attn.in_proj_bias'])
+    lin('sa_out', sd[f'{name}.self_attn.out_proj.weight'], sd[f'{name}.self_attn.out_proj.bias'])
+    wi, bi = sd[f'{name}.multihead_attn.in_proj_weight'], sd[f'{name}.multihead_attn.in_proj_bias']
+    lin('ca_q', wi[:d], bi[:d])
+    lin('ca_kv', wi[d:], bi[d:])
+    lin('ca_out', sd[f'{name}.multihead_attn.out_proj.weight'], sd[f'{name}.multihead_attn.out_proj.bias'])
+    lin('ff1', sd[f'{name}.linear1.weight'], sd[f'{name}.linear1.bias'])
+    lin('ff2', sd[f'{name}.linear2.weight'], sd[f'{name}.linear2.bias'])
+    for k in (1, 2, 3):
+        out[f'ln{k}_g'], out[f'ln{k}_b'] = f32(sd[f'{name}.norm{k}.weight']), f32(sd[f'{name}.norm{k}.bias'])
+    return out
+
+
+def trans_queries(sd: SD, gsd: SD, n_mlp: int, lr_mul: float) -> torch.Tensor:
+    """query = decoder.style(encoder.z) (style_transformer.py:61-66; src/defenses/ours/models.py:311-316): the mapping network
+    (PixelNorm + n_mlp x EqualLinear(lr_mul, fused leaky ReLU); stylegan2/model.py) on the LEARNED z — a constant of the
+    checkpoint, evaluated once at load time in float64.  Returns [n_query, d]."""
+    z = sd['z'][0].double()
+    h = z * torch.rsqrt(torch.mean(z ** 2, dim=-1, keepdim=True) + 1e-8)
+    for k in range(1, n_mlp + 1):
+        w = gsd[f'style.{k}.weight'].double()
+        h = h @ (w * (lr_mul / w.shape[1] ** 0.5)).t() + gsd[f'style.{k}.bias'].double() * lr_mul
+        h = torch.where(h > 0, h, 0.2 * h) * 2 ** 0.5
+    return f32(h)

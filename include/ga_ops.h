@@ -293,8 +293,51 @@ typedef struct ga_pool_denorm_desc {
     const float* x; float* y; const float* dy; float* dx; int N, H, W, k, ld; int backward;
     const float* dy_nchw;     /* backward, optional: a second cotangent on the pooled image as the API returns it, [N,3,H,W]
                                  (MLVGMDefenseModel.__call__(preds_only=False), abstract_models.py:190-193), added to dy */
+    int band;                 /* > 0: the first and last `band` rows of the POOLED image are set to -1 before the de-normalisation
+                                 (y = 0) and pass no gradient — `images[:, :, :32] = -1; images[:, :, -32:] = -1` of
+                                 TransStyleGanDefenseModel.purify (models.py:348-349) at the pooled resolution */
+    int _reserved;
 } ga_pool_denorm_desc;
 int ga_pool_denorm(const ga_pool_denorm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Style-Transformer encoder (src/mlvgms_autoencoders/StyleGan_Trans/models/transformer.py:17-100 as used by GradualStyleEncoder,
+ * models/encoders/style_transformer_encoders.py:33-85) and the resize / crop glue of TransStyleGanDefenseModel.purify
+ * (src/defenses/ours/models.py:299-353).  The linear layers (in_proj, out_proj, FFN) are ga_conv2d 1x1 over the token axis.
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* Core of nn.MultiheadAttention for the encoder's 16 style queries: per (row n, head h)
+ *   P = softmax_over_keys( scale * q_h k_h^T )   [Tq, Tk]        out_h = P v_h        (q, k, v AFTER their input projections)
+ * q: [N, Tq, ldq], k: [N, Tk, ldk], v: [N, Tk, ldv], out: [N, Tq, ldo]; head h = channels [h*dh, (h+1)*dh) of each (pointers may
+ * address the q / k / v thirds of one in_proj output).  p: [N, heads, Tq, Tk], written by the forward, read by the backward.
+ * backward: dout [N, Tq, ldo] given; WRITES dq [N, Tq, lddq], dk [N, Tk, lddk], dv [N, Tk, lddv]; ds: scratch like p.
+ * Tq == 16 and dh == 128 (512 channels, 4 heads) are what the path uses; dh may be any multiple of 16 up to 128, Tq is fixed. */
+typedef struct ga_attn_desc {
+    const float* q; const float* k; const float* v; float* out; float* p;
+    const float* dout; float* ds; float* dq; float* dk; float* dv;
+    int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+    int N, Tq, Tk, heads, dh;
+    float scale;              /* 1 / sqrt(dh) */
+    int backward;
+} ga_attn_desc;
+int ga_attn(const ga_attn_desc* d, void* stream);
+
+/* nn.LayerNorm(C) over the channels of x = a (+ b): y = (x - mean) * rstd * gamma + beta, biased variance, eps inside the root.
+ * a, b, y, dy, dx: [rows, C]; stats: [rows, 2] = (mean, rstd), written forward, read backward.
+ * backward: dx (+)= d loss / d x (the same for both summands a and b). */
+typedef struct ga_layernorm_desc {
+    const float* a; const float* b; const float* gamma; const float* beta; float* y; float* stats;
+    const float* dy; float* dx;
+    long rows; int C; float eps; int backward; int accumulate;
+} ga_layernorm_desc;
+int ga_layernorm(const ga_layernorm_desc* d, void* stream);
+
+/* kornia.geometry.resize(x, 2H) (bilinear, align_corners=False) followed by the row crop x[:, :, crop:-crop] of
+ * TransStyleGanDefenseModel.purify (models.py:307-308: 128 -> 256 px, rows 32:-32): x [N,H,W,C] -> y [N, 2H - 2 crop, 2W, C].
+ * backward: dx (+)= the exact adjoint of dy (border clamping included).  C % 4 == 0. */
+typedef struct ga_resize2_crop_desc {
+    const float* x; float* y; const float* dy; float* dx; int N, H, W, C, crop; int backward; int accumulate; int _reserved;
+} ga_resize2_crop_desc;
+int ga_resize2_crop(const ga_resize2_crop_desc* d, void* stream);
 
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
@@ -394,7 +437,7 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
                   GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21, GA_OP_PIXELNORM = 22, GA_OP_LATENT_MIX = 23,
-                  GA_OP_POOL_DENORM = 24 };
+                  GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -406,6 +449,7 @@ typedef struct ga_op {
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
         ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub; ga_latent_mix_desc lm; ga_pool_denorm_desc pd;
+        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc;
         struct { const float* x; float* y; long rows; int C; } pn;
     } u;
 } ga_op;

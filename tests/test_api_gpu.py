@@ -327,7 +327,7 @@ def test_alpha_objective_verdicts_equal_the_oracles_under_fixed_noise(setup):
     mean_logits = []
     for i in range(0, n, bi):
         x = imgs[i:i + bi].repeat_interleave(eot, dim=0)
-        lg, _ = D.nvae_defender(sd, spec, vsd, vspec, x, alphas, eps, torch.zeros_like(x), 0.0)
+        lg, _ = D.nvae_defender(sd, spec, vsd, vspec, x, alphas, eps, torch.ones_like(x), 0.0)     # a draw is made even at eps 0 (:132)
         mean_logits.append(lg.view(bi, eot, -1).mean(dim=1))
     mean_logits = torch.cat(mean_logits)
     labels = mean_logits.argmax(dim=1).clone()

@@ -140,8 +140,8 @@ def test_no_cpu_fallback():
         CelebaIdentityClassifier('/nonexistent', 'cpu')
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         Engine.bare(2, device='cpu')
-    with pytest.raises(NotImplementedError):
-        TransStyleGanDefenseModel()
+    with pytest.raises(RuntimeError, match='GPU only'):          # the Style-Transformer defender is a GPU path like the others
+        TransStyleGanDefenseModel(None, '/nonexistent', [0.0] * 16, device='cpu')
 
 
 def test_pgd_step_and_protocol_on_a_toy_net():
@@ -345,3 +345,30 @@ def test_every_reference_config_is_present_and_parses():
             exp = name[:-5].split('_')[-1]
             assert len(y['interpolation_alphas']) == n_alpha[exp], name
             assert {'autoencoder_path', 'alpha_attenuation', 'initial_noise_eps', 'gaussian_blur_input'} <= set(y)
+
+
+def test_trans_defense_plans_build_without_a_gpu():
+    """resize + crop -> IR-SE trunk -> 3 transformer decoder layers -> latent mixing -> synthesis -> pool / band / resize ->
+    ResNeXt as one plan pair (engine_trans.build_trans_defense), and the order of the decoder layer's backward ops"""
+    from gen_adversarial_amd.trans_spec import build_trans_spec, init_trans_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    tspec, tsd = build_trans_spec(4, (1, 1, 1, 1)), init_trans_state_dict(4, 1, (1, 1, 1, 1))
+    gspec = build_stylegan_spec(32, width_div=8, style_dim=tspec.d_model)
+    gsd = init_stylegan_state_dict(gspec, 2)
+    cspec, csd = build_resnet_spec(4, 2, (1, 1, 1, 1), 4, 8), init_resnet_state_dict(4, 2, 3, (1, 1, 1, 1), 4, 8)
+    eng = Engine.bare(4, device='cpu', dry_run=True, rep=2, resolution=(3, 64, 64), alphas=[0.1] * 16, share_encoder=True)
+    eng.build_trans_defense(tsd, tspec, gsd, gspec, torch.zeros(16, tspec.d_model), csd, cspec, pool_to=32, mid=128, crop=16)
+    f, b = eng.fwd.names, eng.bwd.names
+    order = [f.index(n) for n in ('image_in', 'trans.resize_crop', 'e4e.input.conv', 'trans.transformerlayer_coarse.sa.in_proj',
+                                  'trans.transformerlayer_fine.norm3', 'latent_mix', 'conv1.modulation', 'face_pool_band_resize_denorm', 'resnet.conv1')]
+    assert order == sorted(order)
+    p = 'trans.transformerlayer_fine.'
+    want = ['norm3^T', 'norm3.residual^T', 'ff.linear2^T', 'ff.linear1^T', 'norm2^T', 'norm2.residual^T', 'ca.out_proj^T', 'ca.attn^T',
+            'ca.kv_proj^T', 'ca.q_proj^T', 'norm1^T', 'norm1.residual^T', 'sa.out_proj^T', 'sa.attn^T', 'sa.in_proj^T']
+    got = [n[len(p):] for n in b if n.startswith(p)]
+    assert got == want
+    assert not any(n.startswith('trans.transformerlayer_coarse.sa.in_proj^T') for n in b)      # the queries are a constant of the checkpoint
+    assert b.index('latent_mix^T') < b.index(p + 'norm3^T') < b.index('trans.resize_crop^T') < b.index('image_in^T')
+    n_of = {n: d.N for d, n in zip(eng.fwd.descs, eng.fwd.names) if hasattr(d, 'N')}
+    assert n_of['e4e.input.conv'] == 2 and n_of['conv1.conv'] == 4                             # shared encoder: one pass per image
