@@ -132,8 +132,10 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
              x2=None, pro_scale=None, pro_shift=None, pro_act=0, pro_per_row=0,
              addend=None, addend_bcast=False, addend2=None, dact_x=None, dact_scale=None, dact_shift=None, dact_act=0,
              in_hw=None, out_hw=None, n=None, KH=None, KW=None, anchored=False, explicit_out=False,
-             ldx=None, ldy=None, ldadd=None, flags=0):
-        """x, x2, y, addend*, dact_x are torch tensors [N,H,W,C] (or Act.t); shapes are taken from them."""
+             ldx=None, ldy=None, ldadd=None, flags=0, precise=False):
+        """x, x2, y, addend*, dact_x are torch tensors [N,H,W,C] (or Act.t); shapes are taken from them.
+        precise: run this contraction on the exact fp32 MFMA kernel even in 'bf16x3' mode (small GEMMs whose results feed an
+        ill-conditioned step: the q / k projections in front of a softmax over thousands of keys)."""
         d = L.ConvDesc()
         N, Hi, Wi, Cx = x.shape
         d.x, d.ldx = _ptr(x), (ldx or Cx)
@@ -141,7 +143,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         if x2 is not None:
             d.x2, d.ldx2, d.C2 = _ptr(x2), x2.shape[3], x2.shape[3]
         d.w, d.bias = _ptr(w), _ptr(bias)
-        if self.precision == 'bf16x3' and not self.dry_run:
+        if self.precision == 'bf16x3' and not self.dry_run and not precise:
             hi, lo = self.store.split(w)
             d.w_hi, d.w_lo = _ptr(hi), _ptr(lo)
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
@@ -232,6 +234,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         hd = wts['se_w1'].shape[0]
         hid = self.alloc((n, hd))
         gate = self.alloc((n, c))
+        if not hasattr(self, 'small_kinks'):
+            self.small_kinks = []
+        self.small_kinks.append(hid)                        # pre-ReLU hidden units, in call order (parity tests replay their decisions)
         e = L.SeExciteDesc()
         e.t = _ptr(t.t)                                     # fused squeeze + excite (one workgroup per row)
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])

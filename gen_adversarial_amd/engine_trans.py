@@ -46,9 +46,9 @@ class TokenView:
 
 
 class TransBuilder:
-    def _linear(self, name, x, w, b, cout, pro_act=0) -> Act:
+    def _linear(self, name, x, w, b, cout, pro_act=0, precise=False) -> Act:
         y = Act(self, x.n, x.h, 1, cout, name)
-        self.conv(self.fwd, name, x.t, w, y.t, bias=b, K=1, pro_act=pro_act)
+        self.conv(self.fwd, name, x.t, w, y.t, bias=b, K=1, pro_act=pro_act, precise=precise)
         return y
 
     def _attention(self, name, q_t, k_t, v_t, ldq, ldk, Tk, d, nhead, dq_t, dk_t, dv_t) -> Act:
@@ -104,7 +104,9 @@ class TransBuilder:
         d, nh, R = spec.d_model, spec.nhead, self.rows
         p = 'trans.' + name
         # ---- self attention: one GEMM projects q, k and v of the same 16 tokens
-        qkv = self._linear(p + '.sa.in_proj', tgt, w['sa_qkv_w'], w['sa_qkv_b'], 3 * d)
+        # the projections in front of a softmax run on the exact fp32 kernel (a few GFLOP per row): logits of tens (random or
+        # sharp trained heads) turn the split-bf16 kernels' 1e-5 relative error into 1e-3 on the gradient
+        qkv = self._linear(p + '.sa.in_proj', tgt, w['sa_qkv_w'], w['sa_qkv_b'], 3 * d, precise=True)
 
         def third(i):
             return lambda: qkv.g.view(R, 16, 1, 3 * d)[..., i * d:(i + 1) * d]
@@ -118,10 +120,12 @@ class TransBuilder:
         self._bwd_steps.append(bwd_sa)
         t1 = self._add_norm(p + '.norm1', tgt, a, w['ln1_g'], w['ln1_b'], spec.eps, res_needs_grad=tgt_needs_grad)
         # ---- cross attention to the memory tokens
-        q2 = self._linear(p + '.ca.q_proj', t1, w['ca_q_w'], w['ca_q_b'], d)
-        kv = self._linear(p + '.ca.kv_proj', mem, w['ca_kv_w'], w['ca_kv_b'], 2 * d)
+        q2 = self._linear(p + '.ca.q_proj', t1, w['ca_q_w'], w['ca_q_b'], d, precise=True)
         Tm = mem.h
+        kv = Act(self, R, Tm, 1, 2 * d, p + '.ca.kv_proj')
         kvv = kv.t.view(R, Tm, 1, 2 * d)
+        self.conv(self.fwd, p + '.ca.k_proj', mem.t, w['ca_kv_w'][:d], kvv[..., :d], bias=w['ca_kv_b'][:d], K=1, ldy=2 * d, precise=True)
+        self.conv(self.fwd, p + '.ca.v_proj', mem.t, w['ca_kv_w'][d:], kvv[..., d:], bias=w['ca_kv_b'][d:], K=1, ldy=2 * d)
         heads2 = self._attention(p + '.ca.attn', q2.t, kvv[..., :d], kvv[..., d:], d, 2 * d, Tm, d, nh,
                                  lambda: q2.g, lambda: kv.g.view(R, Tm, 1, 2 * d)[..., :d], lambda: kv.g.view(R, Tm, 1, 2 * d)[..., d:])
         c = self._linear(p + '.ca.out_proj', heads2, w['ca_out_w'], w['ca_out_b'], d)

@@ -40,9 +40,13 @@ class Replay:
     so a test can assert (a) the other implementation's gradient equals the oracle's GIVEN its decisions, at full tolerance and
     on every element, and (b) its decisions differ from the oracle's only within `worst_margin` of a tie."""
 
-    def __init__(self, candidates, min_agree: float = 0.999):
+    def __init__(self, candidates, min_agree: float = 0.999, small=()):
         self.cands = [c for c in candidates if c.dim() == 4]
         self.min_agree = min_agree
+        # tensors with fewer than 48 decisions (squeeze-and-excite hidden units, [N, C/16]) cannot be identified by the agreement
+        # of their decisions alone; the other implementation hands them over IN CALL ORDER (`small`: [N, F] tensors) and a site
+        # takes the next one of its shape that disagrees on at most two decisions
+        self.small, self.small_pos = list(small), 0
         self.sites = self.matched = self.flips = self.decisions = 0
         self.worst_margin = 0.0
         self.unmatched = []
@@ -64,6 +68,10 @@ class Replay:
             d2 = self.sign(x[:, :, None, None], what)
             self.sites -= 1
             return None if d2 is None else d2[:, :, 0, 0]
+        if x.dim() == 3:                                        # token tensors [B, T, C]: the engine keeps [B, T, 1, C] (NCHW: [B, C, T, 1])
+            d3 = self.sign(x.permute(0, 2, 1).unsqueeze(-1), what)
+            self.sites -= 1
+            return None if d3 is None else d3.squeeze(-1).permute(0, 2, 1)
         own = x > 0
         if x.dim() != 4:
             self.unmatched.append((what, tuple(x.shape)))
@@ -75,7 +83,18 @@ class Replay:
                 best, best_agree = e, agree
         # a match may disagree on at most 0.1 % of the decisions (one, for small tensors); tensors with fewer than 48 decisions
         # are never matched (a chance agreement would replay a stranger's decisions)
-        if best is None or own.numel() < 48 or (1.0 - best_agree) * own.numel() > max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5:
+        if own.numel() < 48 or best is None:
+            best = None
+            if x.shape[2:] == (1, 1):
+                for i in range(self.small_pos, min(self.small_pos + 4, len(self.small))):
+                    e = self.small[i]
+                    if tuple(e.shape) == tuple(x.shape[:2]) and int(((e > 0) != own[:, :, 0, 0]).sum()) <= 2:
+                        best, self.small_pos = e[:, :, None, None], i + 1
+                        break
+            if best is None:
+                self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)))
+                return None
+        elif (1.0 - best_agree) * own.numel() > max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5:
             self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)))
             return None
         dec = best > 0
@@ -125,9 +144,9 @@ class Replay:
 
 
 @contextmanager
-def replaying(candidates, min_agree: float = 0.999):
+def replaying(candidates, min_agree: float = 0.999, small=()):
     old = dict(_STATE)
-    rp = Replay(candidates, min_agree)
+    rp = Replay(candidates, min_agree, small)
     _STATE.update(flip=False, replay=rp)
     try:
         yield rp

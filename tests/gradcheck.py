@@ -42,7 +42,8 @@ def assert_grad_given_engine_decisions(eng, loss_fn, x, got, tol=1e-3, what='inp
     (different summation order), which moves that SAMPLE's gradient.  Samples (rows) on which this machine's oracle still
     reproduces the golden are compared against the reference's numbers; the others are reported and covered by the
     oracle-replay comparison alone."""
-    with K.replaying(engine_candidates(eng)) as rp:
+    small = [t.detach().float().cpu() for t in getattr(eng, 'small_kinks', [])]      # SE hidden pre-activations, in call order
+    with K.replaying(engine_candidates(eng), small=small) as rp:
         xr = x.detach().clone().requires_grad_(True)
         (g,) = torch.autograd.grad(loss_fn(xr), [xr])
     got = got.detach().cpu().float()
