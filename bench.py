@@ -317,6 +317,76 @@ def secondary_measurements(out, args, device, model, store, x, labels):
     except Exception as ex:
         sec['configs2_e4e_defender'] = {'rows_per_s': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
     free_gpu_memory()
+    # ---- configs[4]: Style-Transformer + StyleGAN2-512 defender, ResNeXt-50, 128 px
+    try:
+        log('secondary: configs[4] Style-Transformer defender ...')
+        sec['configs4_trans_defender'] = trans_defender_measurement(args, device)
+    except Exception as ex:
+        sec['configs4_trans_defender'] = {'rows_per_s': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
+    free_gpu_memory()
+
+
+def build_trans_defender(device, rows, eot, precision):
+    """BASELINE.json configs[4] (configs/ours_learned_blur_cars.yaml: 16 learned alphas x 0.7, Gaussian blur of the input): the
+    Style-Transformer encoder (IR-SE50 at 192 x 256 + 3 decoder layers over 16 queries) + StyleGAN2-512 + ResNeXt-50 32x4d at
+    128 px, random weights of the reference architecture"""
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.trans_spec import build_trans_spec, init_trans_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    with open(os.path.join(ROOT, 'configs', 'ours_learned_blur_cars.yaml')) as f:
+        y = yaml.safe_load(f)
+    alphas = [a * y['alpha_attenuation'] for a in y['interpolation_alphas']]
+    tspec, tsd = build_trans_spec(1), init_trans_state_dict(1, 0)
+    gspec = build_stylegan_spec(512)
+    gsd = init_stylegan_state_dict(gspec, 1)
+    cspec, csd = build_resnet_spec(4, 1, (3, 4, 6, 3), 32, 4), init_resnet_state_dict(4, 1, 2, (3, 4, 6, 3), 32, 4)
+    avg = 0.1 * torch.randn(16, 512, generator=torch.Generator().manual_seed(5))
+    eng = Engine.bare(rows, device=device, precision=precision, rep=eot, resolution=(3, 128, 128), alphas=alphas,
+                      noise_eps=float(y['initial_noise_eps']), blur=bool(y['gaussian_blur_input']), share_encoder=False)
+    eng.build_trans_defense(tsd, tspec, gsd, gspec, avg, csd, cspec, pool_to=128)
+    return eng, y
+
+
+def trans_defender_measurement(args, device, rows=64, eot=32):
+    """configs[4] on one GPU: one PGD-Linf iteration (forward + input gradient) over 2 images x EoT 32 = 64 defender rows in one
+    plan run, literal x.repeat(eot) path.  (The config's "bf16" is the reference's autocast setting; arithmetic here is the
+    engine's fp32-class split-bf16 mode.)"""
+    eng, y = build_trans_defender(device, rows, eot, args.precision)
+    n_img = rows // eot
+    g = torch.Generator(device=device).manual_seed(9)
+    x = torch.rand(n_img, 3, 128, 128, device=device, generator=g)
+    x_adv = x.clone()
+    labels = torch.zeros(n_img, dtype=torch.long, device=device)
+
+    def step():
+        eng.x_in.copy_(x_adv)
+        eng.eps[0].normal_().mul_(eng.eps_std)
+        eng.forward()
+        lg = eng.logits.view(-1, eot, eng.logits.shape[-1]).mean(dim=1)
+        p = torch.softmax(lg, dim=1)
+        p[torch.arange(p.shape[0], device=p.device), labels] -= 1.0
+        eng.dlogits.view(-1, eot, p.shape[-1]).copy_((p / eot).unsqueeze(1).expand(-1, eot, -1))
+        eng.backward()
+        nxt = x_adv + (2.0 / 255.0) * eng.dx.sign()
+        x_adv.copy_(torch.min(torch.max(nxt, x - 8.0 / 255.0), x + 8.0 / 255.0).clamp_(0.0, 1.0))
+    t = _time_steps(step, 5, warm=2)
+    s = eng.stream()
+    f_ms, fc_ms, fn = eng.fwd.time(s, iters=1, per_conv=True)
+    b_ms, bc_ms, bn = eng.bwd.time(s, iters=1, per_conv=True)
+    flops = conv_algorithmic_flops(eng.fwd) + conv_algorithmic_flops(eng.bwd)
+    achieved = flops / ((fc_ms + bc_ms) / 1e3) / 1e12
+    peak = PEAK_BF16X3_TFLOPS if args.precision == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
+    res = {'rows_per_s': rows / t, 'ms_per_step': t * 1e3, 'rows_per_step': rows,
+           'what': f'configs[4]: blur -> resize 256 / crop -> Style-Transformer encoder (IR-SE50 @192x256 + 3 decoder layers) -> StyleGAN2-512 -> '
+                   f'pool / band / resize 128 -> ResNeXt-50 32x4d, {n_img} images x EoT {eot} = {rows} defender rows per PGD step (forward + input '
+                   f'gradient), alphas ours_learned_blur_cars.yaml, {len(eng.fwd)} + {len(eng.bwd)} launches per plan, '
+                   f'{eng.bytes / 1e9:.0f} GB of activations + weights',
+           'roofline': {'bound': 'mfma', 'kernel': 'ga::conv_* (implicit-GEMM conv family)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                        'frac': achieved / peak, 'traffic': None, 'launches_per_plan': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                        'algorithmic_gflop_per_plan': flops / 1e9, 'conv_ms_per_plan': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
+    del eng
+    return res
 
 
 def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):

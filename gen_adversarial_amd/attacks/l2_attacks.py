@@ -17,12 +17,13 @@ What differs from the reference, deliberately:
     accumulate weight gradients that nobody reads (SURVEY.md §3.1);
   * DeepFool / FAB need one input-gradient per class on the SAME forward: they go through `class_gradients`, which issues
     the vector-Jacobian products back to back on one retained graph (the HIP defender replays its backward plan per call).
-  * DeepFool, FAB, APGD, AutoAttack and FGSM are BATCHED over images (`batched = True`): `image` may be
+  * DeepFool, FAB, APGD, AutoAttack, C&W and FGSM are BATCHED over images (`batched = True`): `image` may be
     (B,3,H,W) with `gt_label` (B,), every image attacked independently — per-sample norms, masks, early exits, step sizes and
     bests — while every defender call carries B x EoT rows and every per-class backward pass serves all B images at once
     (one vector-Jacobian pass per class RANK for the whole batch: untargeted.py:526-560, :605-635 issue them per image).  For
     B = 1 the arithmetic is the reference's, operation for operation (tests/golden/attacks_toy.npz); for B > 1 every image's
-    result equals its own B = 1 run (tests/test_attacks_cpu.py).  C&W keeps the one-image protocol.
+    result equals its own B = 1 run (tests/test_attacks_cpu.py).  C&W is batched the same way (per-image Adam state is
+    elementwise; the gradient clip, the early stop and the adaptive c are per image).
 Random draws use `torch.randn_like` per image in the reference's order, so a CPU run under `torch.manual_seed` reproduces
 the reference bit for bit (tests/golden/attacks_*.npz).
 """
@@ -154,6 +155,8 @@ class DeepFool(UntargetedL2Attack):
 
 # ---------------------------------------------------------------------------------------------------------------------
 class CW(UntargetedL2Attack):
+    batched = True
+
     def __init__(self, c: float = 1., kappa: float = 0., steps: int = 64, lr: float = 1e-2, n_restarts: int = 1,
                  early_stopping_steps: int = 16):
         self.c, self.kappa, self.steps, self.lr, self.n_restarts = c, kappa, steps, lr, n_restarts
@@ -167,52 +170,68 @@ class CW(UntargetedL2Attack):
         return torch.max((real - other) + self.kappa, torch.zeros_like(real))
 
     def __call__(self, image, gt_label, net):
-        image, label = image.clone().detach(), gt_label.clone().detach()
-        best_ok, best_adv, best_l2 = False, image.clone(), 0.
-        c = self.c
+        """per image: restarts with an adaptive c, FGSM + noise start, Adam on w = atanh(2x - 1) with the gradient clipped to norm 1,
+        early stop once a fooling iterate stops improving (:363-467).  Every piece of state is per image; an image that stopped
+        early keeps its iterate frozen while the others go on."""
+        image, label = image.clone().detach(), gt_label.clone().detach().view(-1)
+        B, dev = image.shape[0], image.device
+        best_ok = torch.zeros(B, dtype=torch.bool, device=dev)
+        best_adv, best_l2 = image.clone(), torch.zeros(B, device=dev)
+        c = torch.full((B,), float(self.c), device=dev)
         res = np.log2(image.shape[-1])
         init = FGSM(l2_bound=np.power(2, res - 5))                  # FGSM start scaled with the image size (:363-365)
         for _ in range(self.n_restarts):
             run_adv = init(image, label, net)[2]
-            noise = torch.randn_like(image)
-            noise = noise * np.power(2, res - 8) / torch.norm(noise.view(1, -1), dim=1, keepdim=True)
+            noise = _per_image_randn(image)
+            noise = noise * np.power(2, res - 8) / _bc(torch.norm(noise.view(B, -1), dim=1), noise)
             run_adv = torch.clamp(run_adv + noise, min=1e-6, max=1 - 1e-6)
-            run_l2 = torch.linalg.norm((run_adv - image).flatten(), ord=2)
+            run_l2 = (run_adv - image).flatten(1).norm(dim=1)
             w = torch.atanh(run_adv * 2. - 1).requires_grad_(True)
             opt = torch.optim.Adam([w], lr=self.lr)
-            mean_loss, n_mean, run_ok = 0.0, 0, False
+            mean_loss = torch.zeros(B, device=dev)
+            n_mean = torch.zeros(B, dtype=torch.long, device=dev)
+            run_ok = torch.zeros(B, dtype=torch.bool, device=dev)
+            first = torch.ones(B, dtype=torch.bool, device=dev)      # no iterate recorded yet ("not run_ok" of the first pass)
+            active = torch.ones(B, dtype=torch.bool, device=dev)
             for _step in range(self.steps):
                 with torch.enable_grad():
                     cur = 0.5 * (torch.tanh(w) + 1)
                     logits = net(cur)
-                    loss = nn.functional.mse_loss(cur, image, reduction='sum') + c * self.margin(logits, label)
+                    loss = ((cur - image) ** 2).flatten(1).sum(dim=1) + c * self.margin(logits, label)      # (B,)
                     opt.zero_grad()
-                    (gw,) = torch.autograd.grad(loss, [w])
-                w.grad = gw
-                torch.nn.utils.clip_grad_norm_([w], max_norm=1.)
+                    (gw,) = torch.autograd.grad(loss.sum(), [w])
+                coef = torch.clamp(1.0 / (gw.flatten(1).norm(dim=1) + 1e-6), max=1.0)                      # clip_grad_norm_(max_norm=1), per image
+                w.grad = gw * _bc(coef, gw)
+                w_prev = w.detach().clone()
                 opt.step()
-                fooled = bool((torch.argmax(logits.detach(), 1) != label).item())
-                if fooled:
-                    lv = loss.detach().item()
-                    if lv > mean_loss and n_mean > self.early_stopping_len:
-                        break                                       # fooling but not converging any more
-                    look = min(n_mean, self.early_stopping_len)
-                    mean_loss = (mean_loss * look + lv) / (look + 1)
-                    n_mean += 1
-                this_l2 = torch.linalg.norm((cur.detach() - image).flatten(), ord=2)
-                if not run_ok or run_l2 > this_l2:
-                    run_adv, run_l2, run_ok = cur.detach(), this_l2, fooled
+                with torch.no_grad():
+                    w.copy_(torch.where(_bc(active, w), w, w_prev))                                          # stopped images stay put
+                fooled = torch.argmax(logits.detach(), 1) != label
+                lv = loss.detach()
+                stop = active & fooled & (lv > mean_loss) & (n_mean > self.early_stopping_len)               # fooling but not converging any more
+                upd = active & fooled & ~stop
+                look = torch.minimum(n_mean, torch.full_like(n_mean, self.early_stopping_len)).to(lv.dtype)
+                mean_loss = torch.where(upd, (mean_loss * look + lv) / (look + 1), mean_loss)
+                n_mean = n_mean + upd.long()
+                active = active & ~stop
+                this_l2 = (cur.detach() - image).flatten(1).norm(dim=1)
+                take = active & (first | ~run_ok | (run_l2 > this_l2))
+                run_adv = torch.where(_bc(take, run_adv), cur.detach(), run_adv)
+                run_l2 = torch.where(take, this_l2, run_l2)
+                run_ok = torch.where(take, fooled, run_ok)
+                first = first & ~take
+                if not bool(active.any()):
+                    break
             with torch.no_grad():
-                fooled = bool((torch.argmax(net(run_adv), 1) != label).item())
-            if not fooled:
-                c = 1.2 * c
-            elif (not best_ok) or best_l2 > run_l2:
-                c = 0.8 * c
-                best_adv, best_l2, best_ok = run_adv, run_l2, True
-            elif best_l2 < run_l2:
-                c = 0.9 * c
-            c = max(min(c, 1000), 0.1)
-        return best_ok, best_l2, best_adv
+                fooled = torch.argmax(net(run_adv), 1) != label
+            improve = fooled & (~best_ok | (best_l2 > run_l2))
+            worse = fooled & ~improve & (best_l2 < run_l2)
+            c = torch.where(~fooled, 1.2 * c, torch.where(improve, 0.8 * c, torch.where(worse, 0.9 * c, c)))
+            best_adv = torch.where(_bc(improve, best_adv), run_adv, best_adv)
+            best_l2 = torch.where(improve, run_l2, best_l2)
+            best_ok = best_ok | improve
+            c = c.clamp(0.1, 1000.0)
+        return _ret(best_ok, best_l2, best_adv)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

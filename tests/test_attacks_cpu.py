@@ -95,7 +95,7 @@ def _content_noise(image):
     return torch.cat(out, dim=0)
 
 
-@pytest.mark.parametrize('name', ['fgsm', 'deepfool', 'apgd_ce', 'apgd_dlr', 'fab'])
+@pytest.mark.parametrize('name', ['fgsm', 'deepfool', 'apgd_ce', 'apgd_dlr', 'fab', 'cw'])
 def test_batched_attack_equals_the_one_image_runs(name, gold, monkeypatch):
     from gen_adversarial_amd.attacks import l2_attacks
     monkeypatch.setattr(l2_attacks, '_per_image_randn', _content_noise)
@@ -114,7 +114,7 @@ def test_batched_attack_equals_the_one_image_runs(name, gold, monkeypatch):
         if bool(s1):
             assert float(b[i]) == pytest.approx(float(b1), rel=1e-5, abs=1e-6), (name, i)
         np.testing.assert_allclose(a[i:i + 1].detach().numpy(), a1.detach().numpy(), atol=1e-5, err_msg=f'{name} {i}')
-    assert bool(s[3]) and float(b[3]) == 0.0 or name.startswith('apgd')       # APGD has no "already misclassified" exit (:246-322)
+    assert bool(s[3]) and float(b[3]) == 0.0 or name.startswith('apgd') or name == 'cw'    # APGD / C&W have no "already misclassified" exit
 
 
 def test_batched_autoattack_equals_the_one_image_runs(gold, monkeypatch):
