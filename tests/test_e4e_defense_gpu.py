@@ -322,3 +322,40 @@ def test_latent_avg_is_estimated_when_the_checkpoint_has_none(tmp_path):
     assert torch.equal(w.latent_avg[0], w.latent_avg[-1])                       # one mean latent, repeated over the indices
     spread = S.mapping_network(gsd, z).std(dim=0).max().item() / 100.0          # standard error of a 10000-sample mean
     assert (w.latent_avg[0] - ref[0]).abs().max().item() < 6 * spread + 1e-3
+
+
+def test_bpda_on_the_e4e_defender():
+    """Engine.backward(identity_purifier=True) for the e4e defender (classifier input in space-to-depth form): dx[image] = sum
+    over its EoT replicas of the classifier's input gradient at the purified image; needs equal input and purified sizes"""
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    size = res = 64
+    espec, esd = build_e4e_spec(size, 4, (1, 1, 1, 1)), init_e4e_state_dict(size, 4, 3, (1, 1, 1, 1))
+    gspec = build_stylegan_spec(size, width_div=8, style_dim=espec.style_dim)
+    gsd = init_stylegan_state_dict(gspec, 4)
+    cspec, csd = build_resnet_spec(2, 8, (1, 1, 1, 1)), init_resnet_state_dict(2, 8, 5, (1, 1, 1, 1))
+    rows, rep = 6, 3
+    eng = Engine.bare(rows, device=DEV, rep=rep, resolution=(3, res, res), alphas=[0.1] * gspec.n_latent, share_encoder=True)
+    eng.build_e4e_defense(esd, espec, gsd, gspec, None, csd, cspec, pool_to=size)
+    assert eng.bpda is not None
+    g = torch.Generator().manual_seed(8)
+    eng.x_in.copy_(torch.rand(rows // rep, 3, res, res, generator=g).to(DEV))
+    eng.eps[0].copy_(torch.randn(eng.eps[0].shape, generator=g).to(DEV))
+    eng.forward()
+    eng.dlogits.view(rows, -1).copy_(torch.randn(rows, 2, generator=g).to(DEV))
+    eng.backward()                                            # full white-box gradient: also leaves d loss / d purified in place
+    full = eng.dx.clone()
+    t = eng.purified_s2d.g
+    n, h2, w2, _ = t.shape
+    dp = t.view(n, h2, w2, 2, 2, 8)[..., :3].permute(0, 5, 1, 3, 2, 4).reshape(n, 3, 2 * h2, 2 * w2)      # as purified_nchw() reads .t
+    eng.backward(identity_purifier=True)
+    want = dp.view(rows // rep, rep, 3, res, res).sum(dim=1)
+    assert torch.allclose(eng.dx, want, atol=1e-6 * max(1.0, want.abs().max().item()))
+    assert not torch.allclose(eng.dx, full, atol=1e-3 * full.abs().max().item())       # BPDA is not the white-box gradient
+    small = Engine.bare(2, device=DEV, rep=1, resolution=(3, res, res), alphas=[0.1] * gspec.n_latent)
+    small.build_e4e_defense(esd, espec, gsd, gspec, None, csd, cspec, pool_to=32)       # purified smaller than the input: no identity
+    assert small.bpda is None
+    with pytest.raises(RuntimeError):
+        small.backward(identity_purifier=True)
