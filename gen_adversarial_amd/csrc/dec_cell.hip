@@ -1,0 +1,405 @@
+// ga_dec_cell — the residual branch of NVAE's ResidualCellDecoder (reference: NVAE/modules/architecture.py:139-186,
+// BN -> 1x1 (C -> 6C) -> BN -> SiLU -> depthwise 5x5 -> BN -> SiLU -> 1x1 (6C -> C) -> BN, BatchNorms folded) in ONE launch.
+//
+// Unfused, the two 6C-wide tensors cross HBM ten times per cell (forward + backward) and bound the decoder; here they
+// never leave the CU.  A workgroup (4 waves) owns M = 128 TMW pixels = whole images (no halo to exchange) and walks the
+// hidden width in chunks of 32 channels:
+//   GEMM1  t1c [M x 32] = x [M x C] . W1c            x stays resident in registers as split-bf16 MFMA A-fragments
+//   SiLU   -> LDS plane P1 (fp32, [pixel][32 + 8 pad], each image framed by a 2-pixel zero border)
+//   dw5    t2c = taps * P1 + bd                      thread = (channel quad, strip of SW adjacent pixels), as ga_dwconv5
+//   SiLU   -> split-bf16 -> LDS planes P2 (hi, lo)   the A operand of
+//   GEMM2  acc [M x C] += s2c [M x 32] . W2c         accumulators resident in registers (the other half of the budget)
+// The weights' B-fragments are read straight from global memory (L1 / L2 resident: all workgroups walk them together).
+// Contractions are the three-MFMA split-bf16 products of conv_bf3 (same operand split, same k order), the depthwise
+// part is the fp32 loop of dwconv5 in the same order: the fused result follows the unfused one to summation order.
+//
+// Backward (d loss / d t1 from d loss / d t3; d x is then ONE 1x1 ga_conv2d of it): x AND dt3 = dout * ps[n] + pb[n]
+// resident as A-fragments; per chunk t1c and t2c are recomputed (GEMM1 + dw5), then
+//   GEMM3  g [M x 32] = dt3 [M x C] . W2c^T ;  g *= SiLU'(t2c) ;  dw5^T through the same LDS plane ;  *= SiLU'(t1c) -> HBM.
+// Register budget per lane (one workgroup per CU, 512 registers): forward 128 (x) + 128 (acc), backward 128 + 128 (dt3).
+#include "ga_common.h"
+
+namespace ga {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DC_CH = 32;       // hidden channels per chunk
+constexpr int DC_PS = 40;       // floats per pixel of an fp32 LDS plane (32 + 8 pad)
+constexpr int DC_LDB = 40;      // bf16 per pixel of a bf16 LDS plane (80 B rows: conflict-free 16-B fragment reads)
+
+struct dc_geom { int lw, lhw, W, HW, PW, PH; };      // log2 W, log2 (H W); padded plane = (H + 4) x (W + 4)
+
+__device__ __forceinline__ void split8(const floatx4 a, const floatx4 b, bf16x8& hi, bf16x8& lo) {
+    const bf16x4 ha = __builtin_convertvector(a, bf16x4), hb = __builtin_convertvector(b, bf16x4);
+    const bf16x4 la = __builtin_convertvector(a - __builtin_convertvector(ha, floatx4), bf16x4);
+    const bf16x4 lb = __builtin_convertvector(b - __builtin_convertvector(hb, floatx4), bf16x4);
+    hi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// index of workgroup-local pixel p in the framed plane
+__device__ __forceinline__ int plane_idx(const int p, const dc_geom& g) {
+    const int ni = p >> g.lhw, rem = p & (g.HW - 1);
+    return (ni * g.PH + (rem >> g.lw) + 2) * g.PW + (rem & (g.W - 1)) + 2;
+}
+
+// acc[i] += A[i] . B for the resident A-fragments of TMW 32-pixel tiles over K = 16 KS; B rows at wh / wl (row = this lane's
+// output column, 8 lh already added), contiguous along K
+template <int TMW, int KS>
+__device__ __forceinline__ void gemm_resident(floatx16 (&acc)[TMW], const bf16x8 (&ah)[TMW][KS], const bf16x8 (&al)[TMW][KS],
+                                              const __bf16* wh, const __bf16* wl) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wh + ks * 16);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wl + ks * 16);
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bl, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bh, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+// depthwise 5x5 of SW adjacent pixels x 4 channels from a framed plane; base = top-left of the (5 x (SW + 4)) window
+template <int SW>
+__device__ __forceinline__ void dw_strip(floatx4 (&acc)[SW], const float* base, const float* taps, const int PW) {
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < SW; ++j) acc[j] = zero;
+#pragma unroll 1
+    for (int kh = 0; kh < 5; ++kh) {
+        floatx4 w5[5], in[SW + 4];
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) w5[kw] = *reinterpret_cast<const floatx4*>(taps + (kh * 5 + kw) * DC_CH);
+#pragma unroll
+        for (int j = 0; j < SW + 4; ++j) in[j] = *reinterpret_cast<const floatx4*>(base + (kh * PW + j) * DC_PS);
+#pragma unroll
+        for (int j = 0; j < SW; ++j)
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) acc[j] += in[j + kw] * w5[kw];
+    }
+}
+
+__device__ __forceinline__ float silu_f(const float v) { return v * fast_sigmoid(v); }
+__device__ __forceinline__ float dsilu_f(const float v) { const float s = fast_sigmoid(v); return s * (1.0f + v * (1.0f - s)); }
+
+template <int C, int TMW>
+__global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
+    constexpr int M = 128 * TMW, KS = C / 16, NT = C / 32, SW = 4 * TMW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wS = smem;                                                   // [25][32] taps of the chunk
+    float* P1 = smem + 25 * DC_CH;                                      // framed fp32 plane
+    const int plane_px = (M >> gm.lhw) * gm.PH * gm.PW;
+    __bf16* P2h = reinterpret_cast<__bf16*>(P1 + plane_px * DC_PS);     // [M][DC_LDB] bf16, hi then lo
+    __bf16* P2l = P2h + M * DC_LDB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lh = lane >> 5;
+    const int c4 = tid & 7, strip = tid >> 3;
+    const size_t pix0 = (size_t)blockIdx.x * M;
+    const int wb = wave * 32 * TMW;
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
+
+    bf16x8 xh[TMW][KS], xl[TMW][KS];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float* p = d.x + (pix0 + wb + i * 32 + lrow) * C + ks * 16 + 8 * lh;
+            split8(*reinterpret_cast<const floatx4*>(p), *reinterpret_cast<const floatx4*>(p + 4), xh[i][ks], xl[i][ks]);
+        }
+    floatx16 acc[TMW][NT];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this thread's strip of SW pixels (one image row segment) and its window in the framed plane
+    const int p0 = strip * SW;
+    const int win = plane_idx(p0, gm) - 2 * gm.PW - 2;
+    __syncthreads();
+
+    const int nch = d.Hd / DC_CH;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int h0 = ch * DC_CH;
+        // ---- GEMM1 + SiLU -> P1
+        floatx16 t1[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
+        gemm_resident<TMW, KS>(t1, xh, xl, reinterpret_cast<const __bf16*>(d.w1_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
+                               reinterpret_cast<const __bf16*>(d.w1_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
+        if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) =
+            *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
+        const float b1v = d.b1[h0 + lrow];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                P1[plane_idx(row, gm) * DC_PS + lrow] = silu_f(t1[i][r] + b1v);
+            }
+        __syncthreads();
+        // ---- depthwise 5x5 + SiLU -> split-bf16 planes
+        {
+            floatx4 a[SW];
+            dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
+            const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                floatx4 v = a[j] + bd4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
+                *reinterpret_cast<bf16x4*>(P2h + (p0 + j) * DC_LDB + 4 * c4) = hi;
+                *reinterpret_cast<bf16x4*>(P2l + (p0 + j) * DC_LDB + 4 * c4) = lo;
+            }
+        }
+        __syncthreads();
+        // ---- GEMM2: acc += s2c . W2c
+        {
+            bf16x8 ah[TMW][2], al[TMW][2];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int o = (wb + i * 32 + lrow) * DC_LDB + ks * 16 + 8 * lh;
+                    ah[i][ks] = *reinterpret_cast<const bf16x8*>(P2h + o);
+                    al[i][ks] = *reinterpret_cast<const bf16x8*>(P2l + o);
+                }
+            const __bf16* w2h = reinterpret_cast<const __bf16*>(d.w2_hi) + (size_t)lrow * d.Hd + h0 + 8 * lh;
+            const __bf16* w2l = reinterpret_cast<const __bf16*>(d.w2_lo) + (size_t)lrow * d.Hd + h0 + 8 * lh;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w2h + (size_t)j * 32 * d.Hd + ks * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w2l + (size_t)j * 32 * d.Hd + ks * 16);
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bl, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bh, acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // the next chunk's P1 / taps writes come after this chunk's second barrier (every strip is done reading them);
+        // its P2 writes come after its own first barrier (every wave is done with this chunk's fragments by then)
+    }
+    // ---- t3 = acc + b2
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float b2v = d.b2[j * 32 + lrow];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                d.y[(pix0 + row) * C + j * 32 + lrow] = acc[i][j][r] + b2v;
+            }
+    }
+}
+
+template <int C, int TMW>
+__global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
+    constexpr int M = 128 * TMW, KS = C / 16, SW = 4 * TMW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* wS = smem;                                                   // [25][32] forward taps of the chunk
+    float* wT = smem + 25 * DC_CH;                                      // [25][32] flipped taps
+    float* P1 = smem + 50 * DC_CH;                                      // framed fp32 plane: silu(t1c), later dt2c
+    const int plane_px = (M >> gm.lhw) * gm.PH * gm.PW;
+    float* P4 = P1 + plane_px * DC_PS;                                  // [M][DC_PS] t1c (pre-activation)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lh = lane >> 5;
+    const int c4 = tid & 7, strip = tid >> 3;
+    const size_t pix0 = (size_t)blockIdx.x * M;
+    const int wb = wave * 32 * TMW;
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
+
+    bf16x8 xh[TMW][KS], xl[TMW][KS], gh[TMW][KS], gl[TMW][KS];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i) {
+        const size_t gp = pix0 + wb + i * 32 + lrow;
+        const size_t n = gp >> gm.lhw;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = ks * 16 + 8 * lh;
+            const float* p = d.x + gp * C + k;
+            split8(*reinterpret_cast<const floatx4*>(p), *reinterpret_cast<const floatx4*>(p + 4), xh[i][ks], xl[i][ks]);
+            const float* q = d.dout + gp * C + k;
+            const float* s = d.pro_scale + n * C + k;
+            const float* t = d.pro_shift + n * C + k;
+            const floatx4 a = *reinterpret_cast<const floatx4*>(q) * *reinterpret_cast<const floatx4*>(s) + *reinterpret_cast<const floatx4*>(t);
+            const floatx4 b = *reinterpret_cast<const floatx4*>(q + 4) * *reinterpret_cast<const floatx4*>(s + 4) + *reinterpret_cast<const floatx4*>(t + 4);
+            split8(a, b, gh[i][ks], gl[i][ks]);
+        }
+    }
+    const int p0 = strip * SW;
+    const int ctr = plane_idx(p0, gm);
+    const int win = ctr - 2 * gm.PW - 2;
+    __syncthreads();
+
+    const int nch = d.Hd / DC_CH;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int h0 = ch * DC_CH;
+        // ---- (a) recompute t1c -> P4, silu(t1c) -> P1
+        floatx16 t1[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
+        gemm_resident<TMW, KS>(t1, xh, xl, reinterpret_cast<const __bf16*>(d.w1_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
+                               reinterpret_cast<const __bf16*>(d.w1_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
+        if (tid < 200) {
+            *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) =
+                *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
+            *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) =
+                *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
+        }
+        const float b1v = d.b1[h0 + lrow];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = t1[i][r] + b1v;
+                P4[row * DC_PS + lrow] = v;
+                P1[plane_idx(row, gm) * DC_PS + lrow] = silu_f(v);
+            }
+        __syncthreads();
+        // ---- (b) t2c = dw5(silu(t1c)) + bd  ->  silu'(t2c) in registers
+        floatx4 g2[SW];
+        {
+            dw_strip<SW>(g2, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
+            const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < SW; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g2[j][e] = dsilu_f(g2[j][e] + bd4[e]);
+        }
+        // ---- (c) g = dt3 . W2c^T (after the depthwise pass: its registers are free again)
+        floatx16 g[TMW];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g[i][r] = 0.f;
+        gemm_resident<TMW, KS>(g, gh, gl, reinterpret_cast<const __bf16*>(d.w2_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
+                               reinterpret_cast<const __bf16*>(d.w2_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
+        __syncthreads();                // every strip is done reading silu(t1c)
+        // ---- (d) the plane now carries W2c^T dt3 ...
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                P1[plane_idx(row, gm) * DC_PS + lrow] = g[i][r];
+            }
+        __syncthreads();
+        // ---- (e) ... times silu'(t2c), each thread on its own strip
+#pragma unroll
+        for (int j = 0; j < SW; ++j) {
+            floatx4* q = reinterpret_cast<floatx4*>(P1 + (ctr + j) * DC_PS + 4 * c4);
+            *q = *q * g2[j];
+        }
+        __syncthreads();
+        // ---- (f) dw5^T, times silu'(t1c) -> dt1
+        {
+            floatx4 a[SW];
+            dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wT + 4 * c4, gm.PW);
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                const floatx4 u = *reinterpret_cast<const floatx4*>(P4 + (p0 + j) * DC_PS + 4 * c4);
+                floatx4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = a[j][e] * dsilu_f(u[e]);
+                *reinterpret_cast<floatx4*>(d.y + (pix0 + p0 + j) * d.Hd + h0 + 4 * c4) = o;
+            }
+        }
+        __syncthreads();                // P1, P4 and the taps are rewritten by the next chunk
+    }
+}
+
+static int log2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+constexpr size_t DC_LDS_MAX = 160 * 1024;
+
+// M pixels per workgroup for channel count C (0: no kernel)
+static int dc_tile_pixels(int C) { return C == 128 ? 256 : C == 256 ? 128 : 0; }
+
+static size_t dc_lds_bytes(int M, int H, int W, bool bwd) {
+    const size_t plane_px = (size_t)(M / (H * W)) * (H + 4) * (W + 4);
+    return bwd ? (size_t)(50 * DC_CH + plane_px * DC_PS + (size_t)M * DC_PS) * 4
+               : (size_t)(25 * DC_CH + plane_px * DC_PS) * 4 + (size_t)2 * M * DC_LDB * 2;
+}
+
+template <int C, int TMW>
+static int launch_dec_cell(const ga_dec_cell_desc& d, const dc_geom& gm, hipStream_t stream) {
+    constexpr int M = 128 * TMW;
+    const size_t lds = dc_lds_bytes(M, d.H, d.W, d.backward != 0);
+    const dim3 grid((unsigned)((size_t)d.N * d.H * d.W / M));
+    if (d.backward) {
+        static size_t attr = 0;
+        if (lds > attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cell_bwd_kernel<C, TMW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_E_LAUNCH;
+            attr = lds;
+        }
+        hipLaunchKernelGGL((dec_cell_bwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
+    } else {
+        static size_t attr = 0;
+        if (lds > attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cell_fwd_kernel<C, TMW>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_E_LAUNCH;
+            attr = lds;
+        }
+        hipLaunchKernelGGL((dec_cell_fwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
+    }
+    return check_launch();
+}
+
+}  // namespace ga
+
+extern "C" int ga_dec_cell_supported(int N, int H, int W, int C, int Hd) {
+    using namespace ga;
+    const int M = dc_tile_pixels(C);
+    if (!M || N <= 0 || H <= 0 || W <= 0 || Hd <= 0 || Hd % DC_CH) return 0;
+    if (log2_exact(W) < 0 || log2_exact(H) < 0) return 0;
+    const long HW = (long)H * W;
+    if (HW > M || M % HW || W % (M / 32)) return 0;          // whole images per workgroup, strips inside one image row
+    if (((long)N * HW) % M) return 0;
+    return dc_lds_bytes(M, H, W, true) <= DC_LDS_MAX && dc_lds_bytes(M, H, W, false) <= DC_LDS_MAX;
+}
+
+extern "C" int ga_dec_cell(const ga_dec_cell_desc* dp, void* stream_) {
+    ga::clear_stale_error();
+    using namespace ga;
+    if (!dp) return GA_E_BADARG;
+    const ga_dec_cell_desc& d = *dp;
+    if (!d.x || !d.w1_hi || !d.w1_lo || !d.b1 || !d.wd || !d.bd || !d.w2_hi || !d.w2_lo || !d.y) return GA_E_BADARG;
+    if (d.backward ? (!d.dout || !d.pro_scale || !d.pro_shift || !d.wd_bwd) : !d.b2) return GA_E_BADARG;
+    if (!ga_dec_cell_supported(d.N, d.H, d.W, d.C, d.Hd)) return GA_E_UNSUPPORTED;
+    const void* ptrs[] = {d.x, d.w1_hi, d.w1_lo, d.wd, d.wd_bwd, d.bd, d.w2_hi, d.w2_lo, d.dout, d.pro_scale, d.pro_shift, d.y};
+    for (const void* p : ptrs) if (p && !aligned16(p)) return GA_E_ALIGN;
+    dc_geom gm;
+    gm.W = d.W; gm.HW = d.H * d.W; gm.lw = log2_exact(d.W); gm.lhw = log2_exact(gm.HW); gm.PW = d.W + 4; gm.PH = d.H + 4;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    if (d.C == 128) return launch_dec_cell<128, 2>(d, gm, stream);
+    if (d.C == 256) return launch_dec_cell<256, 1>(d, gm, stream);
+    return GA_E_UNSUPPORTED;
+}

@@ -339,6 +339,27 @@ typedef struct ga_resize2_crop_desc {
 } ga_resize2_crop_desc;
 int ga_resize2_crop(const ga_resize2_crop_desc* d, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The residual branch of NVAE's ResidualCellDecoder without up-sampling (NVAE/modules/architecture.py:139-186, BatchNorms
+ * folded), ONE launch per direction; the two Hd = 6C wide tensors live in LDS / registers only (whole images per workgroup):
+ *   forward  (backward = 0): y = t3 [N,H,W,C]   = W2 . silu( dw5( silu(W1 . x + b1) ) + bd ) + b2
+ *   backward (backward = 1): y = dt1 [N,H,W,Hd] = silu'(t1) * dw5^T( silu'(t2) * (W2^T . (dout * pro_scale[n] + pro_shift[n])) )
+ *            with t1 = W1 . x + b1 and t2 = dw5(silu(t1)) + bd recomputed from x; d x follows as one 1x1 ga_conv2d of dt1.
+ * Contractions are the split-bf16 products of ga_conv2d (w*_hi / w*_lo from ga_split_bf16), the depthwise part is fp32.
+ *   w1 [Hd][C];  wd [25][Hd] (tap-major, forward order), wd_bwd the flipped taps;  w2: forward [C][Hd], backward W2^T [Hd][C].
+ * Shapes: ga_dec_cell_supported() (C 128 or 256, H and W powers of two, whole images per 256- / 128-pixel workgroup). */
+typedef struct ga_dec_cell_desc {
+    const float* x;
+    const void* w1_hi; const void* w1_lo; const float* b1;
+    const float* wd; const float* wd_bwd; const float* bd;
+    const void* w2_hi; const void* w2_lo; const float* b2;
+    const float* dout; const float* pro_scale; const float* pro_shift;
+    float* y;
+    int N, H, W, C, Hd; int backward;
+} ga_dec_cell_desc;
+int ga_dec_cell(const ga_dec_cell_desc* d, void* stream);
+int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_dec_cell takes the shape */
+
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
  * x: [rows][C], C % 4 == 0. */
@@ -437,7 +458,7 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
                   GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21, GA_OP_PIXELNORM = 22, GA_OP_LATENT_MIX = 23,
-                  GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27 };
+                  GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27, GA_OP_DEC_CELL = 28 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -449,7 +470,7 @@ typedef struct ga_op {
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
         ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub; ga_latent_mix_desc lm; ga_pool_denorm_desc pd;
-        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc;
+        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc; ga_dec_cell_desc dc;
         struct { const float* x; float* y; long rows; int C; } pn;
     } u;
 } ga_op;
