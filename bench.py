@@ -42,6 +42,13 @@ def conv_algorithmic_flops(plan):
     return total
 
 
+def dec_cell_algorithmic_flops(plan):
+    """2 * MACs of the contractions a fused decoder-cell launch stands for: forward both 1x1 convs, backward the transpose of
+    the second one (the recomputed first conv is extra work, not algorithmic; the first one's transpose is its own ga_conv2d)"""
+    from gen_adversarial_amd import _lib as L
+    return sum(2 * d.N * d.H * d.W * d.C * d.Hd * (1 if d.backward else 2) for d in plan.descs if isinstance(d, L.DecCellDesc))
+
+
 def conv_algorithmic_bytes(plan):
     """bytes every ga_conv2d launch of a plan must move at least once: input(s), weights, output, act' source, addends"""
     from gen_adversarial_amd import _lib as L

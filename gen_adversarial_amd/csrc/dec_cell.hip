@@ -9,7 +9,9 @@
 //   dw5    t2c = taps * P1 + bd                      thread = (channel quad, strip of SW adjacent pixels), as ga_dwconv5
 //   SiLU   -> split-bf16 -> LDS planes P2 (hi, lo)   the A operand of
 //   GEMM2  acc [M x C] += s2c [M x 32] . W2c         accumulators resident in registers (the other half of the budget)
-// The weights' B-fragments are read straight from global memory (L1 / L2 resident: all workgroups walk them together).
+// The weights of a chunk (32 rows of W1, 32 columns of W2: 16 / 32 KB as split bf16) go HBM / L2 -> registers a whole chunk
+// ahead and registers -> LDS at the top of their chunk: the B-fragments are then 16-B LDS reads (read straight from global
+// memory, one exposed L2 round trip per k step made the kernel 2-3x slower: one wave per SIMD hides nothing).
 // Contractions are the three-MFMA split-bf16 products of conv_bf3 (same operand split, same k order), the depthwise
 // part is the fp32 loop of dwconv5 in the same order: the fused result follows the unfused one to summation order.
 //
@@ -28,6 +30,19 @@ constexpr int DC_CH = 32;       // hidden channels per chunk
 constexpr int DC_PS = 40;       // floats per pixel of an fp32 LDS plane (32 + 8 pad)
 constexpr int DC_LDB = 40;      // bf16 per pixel of a bf16 LDS plane (80 B rows: conflict-free 16-B fragment reads)
 
+// -DGA_DC_TRACE (make dctrace -> libga_ops_dctrace.so, tools/dec_cell_trace.py): per-phase shader-clock sums of the chunk
+// loop, lane 0 of every wave of workgroup 0
+#ifdef GA_DC_TRACE
+__device__ unsigned long long ga_dc_trace_buf[4 * 16];
+#define DC_T0 unsigned long long tsum[12] = {}; unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define DC_T(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[i] += tn - tprev; tprev = tn; }
+#define DC_TEND if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) ga_dc_trace_buf[(threadIdx.x >> 6) * 16 + i] = tsum[i]; }
+#else
+#define DC_T0
+#define DC_T(i)
+#define DC_TEND
+#endif
+
 struct dc_geom { int lw, lhw, W, HW, PW, PH; };      // log2 W, log2 (H W); padded plane = (H + 4) x (W + 4)
 
 __device__ __forceinline__ void split8(const floatx4 a, const floatx4 b, bf16x8& hi, bf16x8& lo) {
@@ -42,6 +57,18 @@ __device__ __forceinline__ void split8(const floatx4 a, const floatx4 b, bf16x8&
 __device__ __forceinline__ int plane_idx(const int p, const dc_geom& g) {
     const int ni = p >> g.lhw, rem = p & (g.HW - 1);
     return (ni * g.PH + (rem >> g.lw) + 2) * g.PW + (rem & (g.W - 1)) + 2;
+}
+
+// First pixel of strip s (SW adjacent pixels of one image row).  Consecutive strips are vertically adjacent rows, not
+// horizontal neighbours: a plane row is (W + 4) * 160 B = 128 B mod 256 B for W = 8, 16, ..., so the two strips whose
+// 8 channel-quad lanes share a 16-lane LDS access phase cover all 64 banks (horizontal neighbours, SW * 160 B = 0 mod 256 B
+// apart, met on the same 32).
+template <int SW>
+__device__ __forceinline__ int strip_pixel(const int s, const dc_geom& g) {
+    const int H = g.HW >> g.lw, spr = g.W / SW;                       // strips per image row
+    const int h = s & (H - 1), rest = s >> (g.lhw - g.lw);            // rest = (image, segment)
+    const int seg = rest % spr, ni = rest / spr;
+    return ni * g.HW + h * g.W + seg * SW;
 }
 
 // acc[i] += A[i] . B for the resident A-fragments of TMW 32-pixel tiles over K = 16 KS; B rows at wh / wl (row = this lane's
@@ -82,24 +109,74 @@ __device__ __forceinline__ void dw_strip(floatx4 (&acc)[SW], const float* base, 
     }
 }
 
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+// One chunk of a [rows][K]-major split-bf16 weight matrix through LDS.  ROWMAJOR_K (the expand conv W1 and, backward, W2^T):
+// 32 rows (the chunk's hidden channels) x C columns, LDS pitch C + 8 elements.  Otherwise (the project conv W2, [C][Hd]):
+// C rows x the chunk's 32 columns, LDS pitch 40.  Both pitches are 16 B mod 256 B: the 16-B fragment reads of 16 lanes
+// with consecutive rows fall on 16 distinct bank slots.  256 threads move 16-B pieces; NP pieces per thread and array.
+template <int C, bool ROWS32>
+struct w_chunk {
+    static constexpr int NP = C / 64;
+    static constexpr int PITCH = ROWS32 ? C + 8 : 40;
+    static constexpr int ELEMS = (ROWS32 ? 32 : C) * PITCH;          // bf16 elements of one LDS copy (hi or lo)
+    uintx4 hi[NP], lo[NP];
+    __device__ __forceinline__ void issue(const __bf16* gh, const __bf16* gl, const int ld, const int h0, const int tid) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int q = tid + 256 * k;
+            const size_t o = ROWS32 ? (size_t)(h0 + q / (C / 8)) * ld + (q % (C / 8)) * 8 : (size_t)(q >> 2) * ld + h0 + (q & 3) * 8;
+            hi[k] = *reinterpret_cast<const uintx4*>(gh + o);
+            lo[k] = *reinterpret_cast<const uintx4*>(gl + o);
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* sh, __bf16* sl, const int tid) const {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int q = tid + 256 * k;
+            const int o = ROWS32 ? (q / (C / 8)) * PITCH + (q % (C / 8)) * 8 : (q >> 2) * PITCH + (q & 3) * 8;
+            *reinterpret_cast<uintx4*>(sh + o) = hi[k];
+            *reinterpret_cast<uintx4*>(sl + o) = lo[k];
+        }
+    }
+};
+
 __device__ __forceinline__ float silu_f(const float v) { return v * fast_sigmoid(v); }
 __device__ __forceinline__ float dsilu_f(const float v) { const float s = fast_sigmoid(v); return s * (1.0f + v * (1.0f - s)); }
 
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
     constexpr int M = 128 * TMW, KS = C / 16, NT = C / 32, SW = 4 * TMW;
+    using WA = w_chunk<C, true>;
+    using WB = w_chunk<C, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wS = smem;                                                   // [25][32] taps of the chunk
     float* P1 = smem + 25 * DC_CH;                                      // framed fp32 plane
     const int plane_px = (M >> gm.lhw) * gm.PH * gm.PW;
     __bf16* P2h = reinterpret_cast<__bf16*>(P1 + plane_px * DC_PS);     // [M][DC_LDB] bf16, hi then lo
     __bf16* P2l = P2h + M * DC_LDB;
+    __bf16* W1h = P2l + M * DC_LDB;                                     // the chunk's rows of W1, then its columns of W2
+    __bf16* W1l = W1h + WA::ELEMS;
+    __bf16* W2h = W1l + WA::ELEMS;
+    __bf16* W2l = W2h + WB::ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lh = lane >> 5;
     const int c4 = tid & 7, strip = tid >> 3;
     const size_t pix0 = (size_t)blockIdx.x * M;
     const int wb = wave * 32 * TMW;
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    const __bf16* g1h = reinterpret_cast<const __bf16*>(d.w1_hi);
+    const __bf16* g1l = reinterpret_cast<const __bf16*>(d.w1_lo);
+    const __bf16* g2h = reinterpret_cast<const __bf16*>(d.w2_hi);
+    const __bf16* g2l = reinterpret_cast<const __bf16*>(d.w2_lo);
+
+    // the first chunk's weights are on their way while the plane is cleared and x is split
+    WA wa;
+    WB wq;
+    floatx4 taps = zero;
+    wa.issue(g1h, g1l, C, 0, tid);
+    wq.issue(g2h, g2l, d.Hd, 0, tid);
+    if (tid < 200) taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
 
     for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
 
@@ -120,37 +197,52 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // this thread's strip of SW pixels (one image row segment) and its window in the framed plane
-    const int p0 = strip * SW;
+    const int p0 = strip_pixel<SW>(strip, gm);
     const int win = plane_idx(p0, gm) - 2 * gm.PW - 2;
-    __syncthreads();
+    int prow[TMW][4];                                   // plane index of accumulator rows 8 q (+ 0..3) of each 32-pixel tile
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) prow[i][q] = plane_idx(wb + i * 32 + 8 * q + 4 * lh, gm) * DC_PS + lrow;
 
     const int nch = d.Hd / DC_CH;
+    DC_T0
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int h0 = ch * DC_CH;
+        // ---- this chunk's weights: registers -> LDS; the next chunk's: HBM / L2 -> registers, a whole chunk ahead
+        wa.store(W1h, W1l, tid);
+        wq.store(W2h, W2l, tid);
+        if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
+        __syncthreads();
+        DC_T(0)
+        if (ch + 1 < nch) {
+            wa.issue(g1h, g1l, C, h0 + DC_CH, tid);
+            wq.issue(g2h, g2l, d.Hd, h0 + DC_CH, tid);
+            if (tid < 200) taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + DC_CH + 4 * c4);
+        }
         // ---- GEMM1 + SiLU -> P1
         floatx16 t1[TMW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
-        gemm_resident<TMW, KS>(t1, xh, xl, reinterpret_cast<const __bf16*>(d.w1_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
-                               reinterpret_cast<const __bf16*>(d.w1_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
-        if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) =
-            *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
+        DC_T(1)
+        gemm_resident<TMW, KS>(t1, xh, xl, W1h + lrow * WA::PITCH + 8 * lh, W1l + lrow * WA::PITCH + 8 * lh);
+        DC_T(2)
         const float b1v = d.b1[h0 + lrow];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                P1[plane_idx(row, gm) * DC_PS + lrow] = silu_f(t1[i][r] + b1v);
-            }
+            for (int r = 0; r < 16; ++r) P1[prow[i][r >> 2] + (r & 3) * DC_PS] = silu_f(t1[i][r] + b1v);
+        DC_T(3)
         __syncthreads();
+        DC_T(4)
         // ---- depthwise 5x5 + SiLU -> split-bf16 planes
         {
             floatx4 a[SW];
             dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
+            DC_T(5)
             const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
 #pragma unroll
             for (int j = 0; j < SW; ++j) {
@@ -163,7 +255,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
                 *reinterpret_cast<bf16x4*>(P2l + (p0 + j) * DC_LDB + 4 * c4) = lo;
             }
         }
+        DC_T(6)
         __syncthreads();
+        DC_T(7)
         // ---- GEMM2: acc += s2c . W2c
         {
             bf16x8 ah[TMW][2], al[TMW][2];
@@ -175,14 +269,14 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
                     ah[i][ks] = *reinterpret_cast<const bf16x8*>(P2h + o);
                     al[i][ks] = *reinterpret_cast<const bf16x8*>(P2l + o);
                 }
-            const __bf16* w2h = reinterpret_cast<const __bf16*>(d.w2_hi) + (size_t)lrow * d.Hd + h0 + 8 * lh;
-            const __bf16* w2l = reinterpret_cast<const __bf16*>(d.w2_lo) + (size_t)lrow * d.Hd + h0 + 8 * lh;
+            const __bf16* w2h = W2h + lrow * WB::PITCH + 8 * lh;
+            const __bf16* w2l = W2l + lrow * WB::PITCH + 8 * lh;
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w2h + (size_t)j * 32 * d.Hd + ks * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w2l + (size_t)j * 32 * d.Hd + ks * 16);
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w2h + j * 32 * WB::PITCH + ks * 16);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w2l + j * 32 * WB::PITCH + ks * 16);
 #pragma unroll
                     for (int i = 0; i < TMW; ++i) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh, acc[i][j], 0, 0, 0);
@@ -192,9 +286,11 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
                 }
             }
         }
-        // the next chunk's P1 / taps writes come after this chunk's second barrier (every strip is done reading them);
-        // its P2 writes come after its own first barrier (every wave is done with this chunk's fragments by then)
+        DC_T(8)
+        __syncthreads();                // the weight buffers, the taps and P1 are rewritten at the top of the next chunk
+        DC_T(9)
     }
+    DC_TEND
     // ---- t3 = acc + b2
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -212,18 +308,36 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
     constexpr int M = 128 * TMW, KS = C / 16, SW = 4 * TMW;
+    using WA = w_chunk<C, true>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wS = smem;                                                   // [25][32] forward taps of the chunk
     float* wT = smem + 25 * DC_CH;                                      // [25][32] flipped taps
     float* P1 = smem + 50 * DC_CH;                                      // framed fp32 plane: silu(t1c), later dt2c
     const int plane_px = (M >> gm.lhw) * gm.PH * gm.PW;
     float* P4 = P1 + plane_px * DC_PS;                                  // [M][DC_PS] t1c (pre-activation)
+    __bf16* W1h = reinterpret_cast<__bf16*>(P4 + M * DC_PS);            // the chunk's rows of W1, then of W2^T
+    __bf16* W1l = W1h + WA::ELEMS;
+    __bf16* W2h = W1l + WA::ELEMS;
+    __bf16* W2l = W2h + WA::ELEMS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lh = lane >> 5;
     const int c4 = tid & 7, strip = tid >> 3;
     const size_t pix0 = (size_t)blockIdx.x * M;
     const int wb = wave * 32 * TMW;
     const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    const __bf16* g1h = reinterpret_cast<const __bf16*>(d.w1_hi);
+    const __bf16* g1l = reinterpret_cast<const __bf16*>(d.w1_lo);
+    const __bf16* g2h = reinterpret_cast<const __bf16*>(d.w2_hi);
+    const __bf16* g2l = reinterpret_cast<const __bf16*>(d.w2_lo);
+
+    WA wa, wq;
+    floatx4 taps = zero, tapsT = zero;
+    wa.issue(g1h, g1l, C, 0, tid);
+    wq.issue(g2h, g2l, C, 0, tid);
+    if (tid < 200) {
+        taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
+        tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
+    }
 
     for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
 
@@ -245,29 +359,43 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
             split8(a, b, gh[i][ks], gl[i][ks]);
         }
     }
-    const int p0 = strip * SW;
+    const int p0 = strip_pixel<SW>(strip, gm);
     const int ctr = plane_idx(p0, gm);
     const int win = ctr - 2 * gm.PW - 2;
-    __syncthreads();
+    int prow[TMW][4];
+#pragma unroll
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) prow[i][q] = plane_idx(wb + i * 32 + 8 * q + 4 * lh, gm) * DC_PS + lrow;
 
     const int nch = d.Hd / DC_CH;
+    DC_T0
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int h0 = ch * DC_CH;
+        wa.store(W1h, W1l, tid);
+        wq.store(W2h, W2l, tid);
+        if (tid < 200) {
+            *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
+            *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) = tapsT;
+        }
+        __syncthreads();
+        DC_T(0)
+        if (ch + 1 < nch) {
+            wa.issue(g1h, g1l, C, h0 + DC_CH, tid);
+            wq.issue(g2h, g2l, C, h0 + DC_CH, tid);
+            if (tid < 200) {
+                taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + DC_CH + 4 * c4);
+                tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + h0 + DC_CH + 4 * c4);
+            }
+        }
         // ---- (a) recompute t1c -> P4, silu(t1c) -> P1
         floatx16 t1[TMW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
-        gemm_resident<TMW, KS>(t1, xh, xl, reinterpret_cast<const __bf16*>(d.w1_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
-                               reinterpret_cast<const __bf16*>(d.w1_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
-        if (tid < 200) {
-            *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) =
-                *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
-            *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) =
-                *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + h0 + 4 * c4);
-        }
+        gemm_resident<TMW, KS>(t1, xh, xl, W1h + lrow * WA::PITCH + 8 * lh, W1l + lrow * WA::PITCH + 8 * lh);
         const float b1v = d.b1[h0 + lrow];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
@@ -276,9 +404,11 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
                 const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float v = t1[i][r] + b1v;
                 P4[row * DC_PS + lrow] = v;
-                P1[plane_idx(row, gm) * DC_PS + lrow] = silu_f(v);
+                P1[prow[i][r >> 2] + (r & 3) * DC_PS] = silu_f(v);
             }
+        DC_T(1)
         __syncthreads();
+        DC_T(2)
         // ---- (b) t2c = dw5(silu(t1c)) + bd  ->  silu'(t2c) in registers
         floatx4 g2[SW];
         {
@@ -289,24 +419,24 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g2[j][e] = dsilu_f(g2[j][e] + bd4[e]);
         }
+        DC_T(3)
         // ---- (c) g = dt3 . W2c^T (after the depthwise pass: its registers are free again)
         floatx16 g[TMW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[i][r] = 0.f;
-        gemm_resident<TMW, KS>(g, gh, gl, reinterpret_cast<const __bf16*>(d.w2_hi) + (size_t)(h0 + lrow) * C + 8 * lh,
-                               reinterpret_cast<const __bf16*>(d.w2_lo) + (size_t)(h0 + lrow) * C + 8 * lh);
+        gemm_resident<TMW, KS>(g, gh, gl, W2h + lrow * WA::PITCH + 8 * lh, W2l + lrow * WA::PITCH + 8 * lh);
+        DC_T(4)
         __syncthreads();                // every strip is done reading silu(t1c)
+        DC_T(5)
         // ---- (d) the plane now carries W2c^T dt3 ...
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                P1[plane_idx(row, gm) * DC_PS + lrow] = g[i][r];
-            }
+            for (int r = 0; r < 16; ++r) P1[prow[i][r >> 2] + (r & 3) * DC_PS] = g[i][r];
         __syncthreads();
+        DC_T(6)
         // ---- (e) ... times silu'(t2c), each thread on its own strip
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
@@ -314,6 +444,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
             *q = *q * g2[j];
         }
         __syncthreads();
+        DC_T(7)
         // ---- (f) dw5^T, times silu'(t1c) -> dt1
         {
             floatx4 a[SW];
@@ -327,8 +458,11 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
                 *reinterpret_cast<floatx4*>(d.y + (pix0 + p0 + j) * d.Hd + h0 + 4 * c4) = o;
             }
         }
-        __syncthreads();                // P1, P4 and the taps are rewritten by the next chunk
+        DC_T(8)
+        __syncthreads();                // P1, P4, the weight buffers and the taps are rewritten by the next chunk
+        DC_T(9)
     }
+    DC_TEND
 }
 
 static int log2_exact(int v) {
@@ -342,16 +476,17 @@ constexpr size_t DC_LDS_MAX = 160 * 1024;
 // M pixels per workgroup for channel count C (0: no kernel)
 static int dc_tile_pixels(int C) { return C == 128 ? 256 : C == 256 ? 128 : 0; }
 
-static size_t dc_lds_bytes(int M, int H, int W, bool bwd) {
+static size_t dc_lds_bytes(int C, int M, int H, int W, bool bwd) {
     const size_t plane_px = (size_t)(M / (H * W)) * (H + 4) * (W + 4);
-    return bwd ? (size_t)(50 * DC_CH + plane_px * DC_PS + (size_t)M * DC_PS) * 4
-               : (size_t)(25 * DC_CH + plane_px * DC_PS) * 4 + (size_t)2 * M * DC_LDB * 2;
+    const size_t rows32 = (size_t)2 * 32 * (C + 8) * 2, cols32 = (size_t)2 * C * 40 * 2;      // one staged weight chunk, hi + lo
+    return bwd ? (size_t)(50 * DC_CH + plane_px * DC_PS + (size_t)M * DC_PS) * 4 + 2 * rows32
+               : (size_t)(25 * DC_CH + plane_px * DC_PS) * 4 + (size_t)2 * M * DC_LDB * 2 + rows32 + cols32;
 }
 
 template <int C, int TMW>
 static int launch_dec_cell(const ga_dec_cell_desc& d, const dc_geom& gm, hipStream_t stream) {
     constexpr int M = 128 * TMW;
-    const size_t lds = dc_lds_bytes(M, d.H, d.W, d.backward != 0);
+    const size_t lds = dc_lds_bytes(C, M, d.H, d.W, d.backward != 0);
     const dim3 grid((unsigned)((size_t)d.N * d.H * d.W / M));
     if (d.backward) {
         static size_t attr = 0;
@@ -375,6 +510,12 @@ static int launch_dec_cell(const ga_dec_cell_desc& d, const dc_geom& gm, hipStre
 
 }  // namespace ga
 
+#ifdef GA_DC_TRACE
+extern "C" int ga_debug_dc_trace_read(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ga::ga_dc_trace_buf), (size_t)n * 8) == hipSuccess ? GA_OK : GA_E_LAUNCH;
+}
+#endif
+
 extern "C" int ga_dec_cell_supported(int N, int H, int W, int C, int Hd) {
     using namespace ga;
     const int M = dc_tile_pixels(C);
@@ -383,7 +524,7 @@ extern "C" int ga_dec_cell_supported(int N, int H, int W, int C, int Hd) {
     const long HW = (long)H * W;
     if (HW > M || M % HW || W % (M / 32)) return 0;          // whole images per workgroup, strips inside one image row
     if (((long)N * HW) % M) return 0;
-    return dc_lds_bytes(M, H, W, true) <= DC_LDS_MAX && dc_lds_bytes(M, H, W, false) <= DC_LDS_MAX;
+    return dc_lds_bytes(C, M, H, W, true) <= DC_LDS_MAX && dc_lds_bytes(C, M, H, W, false) <= DC_LDS_MAX;
 }
 
 extern "C" int ga_dec_cell(const ga_dec_cell_desc* dp, void* stream_) {

@@ -35,6 +35,10 @@ from .engine_trans import TransBuilder
 
 
 class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransBuilder):
+    # decoder cells whose shape ga_dec_cell takes run as one fused launch per direction (GA_FUSE_DEC_CELL=0: the three
+    # unfused launches, same numbers bit for bit — kept for A/B profiles and for the shapes the fused kernel refuses)
+    fuse_dec_cells = os.environ.get('GA_FUSE_DEC_CELL', '1') != '0'
+
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,

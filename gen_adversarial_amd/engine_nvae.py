@@ -63,16 +63,35 @@ class NvaeBuilder:
         H, W = (2 * h, 2 * w) if up else (h, w)
         hid_c = cell.hidden
         p = cell.prefix
-        t1 = Act(self, n, h, w, hid_c, p + '.t1')
-        t2 = Act(self, n, H, W, hid_c, p + '.t2')
+        # whole-image tiles at 128 / 256 channels: ONE launch per direction, the two hid_c-wide tensors never reach HBM
+        fused = (not up and self.precision == 'bf16x3' and self.fuse_dec_cells
+                 and L.lib.ga_dec_cell_supported(n, H, W, x.c, hid_c) == 1 and cell.cout == x.c)
         t3 = Act(self, n, H, W, cell.cout, p + '.t3')
         out = Act(self, n, H, W, cell.cout, p + '.out')
-        self.conv(self.fwd, p + '.pw1', x.t, wts['w1'], t1.t, bias=wts['b1'], K=1)
-        d = L.DwDesc()
-        d.x, d.w, d.bias, d.y = _ptr(t1.t), _ptr(wts['wd']), _ptr(wts['bd']), _ptr(t2.t)
-        d.N, d.H, d.W, d.C, d.pro_act, d.up2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
-        self.fwd.add(d, p + '.dw5')
-        self.conv(self.fwd, p + '.pw2', t2.t, wts['w2'], t3.t, bias=wts['b2'], K=1, pro_act=L.GA_ACT_SILU)
+
+        def fused_desc(backward: int) -> L.DecCellDesc:
+            f = L.DecCellDesc()
+            f.x, f.b1, f.wd, f.wd_bwd, f.bd, f.b2 = (_ptr(x.t), _ptr(wts['b1']), _ptr(wts['wd']), _ptr(wts['wd_bwd']),
+                                                    _ptr(wts['bd']), _ptr(wts['b2']))
+            if not self.dry_run:
+                (h1, l1), (h2, l2) = self.store.split(wts['w1']), self.store.split(wts['w2_bwd' if backward else 'w2'])
+                f.w1_hi, f.w1_lo, f.w2_hi, f.w2_lo = _ptr(h1), _ptr(l1), _ptr(h2), _ptr(l2)
+            f.N, f.H, f.W, f.C, f.Hd, f.backward = n, H, W, x.c, hid_c, backward
+            return f
+
+        if fused:
+            f = fused_desc(0)
+            f.y = _ptr(t3.t)
+            self.fwd.add(f, p + '.cell')
+        else:
+            t1 = Act(self, n, h, w, hid_c, p + '.t1')
+            t2 = Act(self, n, H, W, hid_c, p + '.t2')
+            self.conv(self.fwd, p + '.pw1', x.t, wts['w1'], t1.t, bias=wts['b1'], K=1)
+            d = L.DwDesc()
+            d.x, d.w, d.bias, d.y = _ptr(t1.t), _ptr(wts['wd']), _ptr(wts['bd']), _ptr(t2.t)
+            d.N, d.H, d.W, d.C, d.pro_act, d.up2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
+            self.fwd.add(d, p + '.dw5')
+            self.conv(self.fwd, p + '.pw2', t2.t, wts['w2'], t3.t, bias=wts['b2'], K=1, pro_act=L.GA_ACT_SILU)
         gate, hid = self.se_forward(p, t3, wts, H * W)
         a = L.SeApplyDesc()
         if up:
@@ -87,14 +106,19 @@ class NvaeBuilder:
 
         def backward():
             ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W)
-            dt2 = self.scratch((n, H, W, hid_c), 'dec_dt2')
-            self.conv(self.bwd, p + '.pw2^T', out.g, wts['w2_bwd'], dt2, K=1,
-                      pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t2.t, dact_act=L.GA_ACT_SILU)
             dt1 = self.scratch((n, h, w, hid_c), 'dec_dt1')
-            b = L.DwDesc()
-            b.x, b.w, b.dact_x, b.y = _ptr(dt2), _ptr(wts['wd_bwd']), _ptr(t1.t), _ptr(dt1)
-            b.N, b.H, b.W, b.C, b.dact_act, b.pool2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
-            self.bwd.add(b, p + '.dw5^T')
+            if fused:
+                b = fused_desc(1)
+                b.dout, b.pro_scale, b.pro_shift, b.y = _ptr(out.g), _ptr(ps), _ptr(pb), _ptr(dt1)
+                self.bwd.add(b, p + '.cell^T')
+            else:
+                dt2 = self.scratch((n, H, W, hid_c), 'dec_dt2')
+                self.conv(self.bwd, p + '.pw2^T', out.g, wts['w2_bwd'], dt2, K=1,
+                          pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t2.t, dact_act=L.GA_ACT_SILU)
+                b = L.DwDesc()
+                b.x, b.w, b.dact_x, b.y = _ptr(dt2), _ptr(wts['wd_bwd']), _ptr(t1.t), _ptr(dt1)
+                b.N, b.H, b.W, b.C, b.dact_act, b.pool2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
+                self.bwd.add(b, p + '.dw5^T')
             self.grad_conv(p + '.pw1^T', dt1, wts['w1_bwd'], x, K=1, primary=None if up else out.g)
             if up:
                 dsl = self.scratch((n, h, w, cell.cout), 'dec_dsl')

@@ -40,7 +40,7 @@ def _torch_cell(x, w1, b1, wd, bd, w2, b2):
     return t1, t2, t3
 
 
-CASES = [(2, 16, 128, 768), (4, 8, 128, 96), (4, 8, 256, 1536), (8, 4, 256, 64), (3, 16, 128, 32)]
+CASES = [(2, 16, 128, 768), (1, 16, 128, 96), (4, 8, 256, 1536), (6, 8, 256, 64), (3, 16, 128, 32)]
 
 
 @pytest.mark.parametrize('N,H,Cc,Hd', CASES)
@@ -126,6 +126,7 @@ def test_dec_cell_refuses_unsupported_shapes():
     assert sup(3, 8, 8, 128, 768) == 0             # rows do not fill whole workgroups (4 images each)
     assert sup(2, 16, 16, 128, 100) == 0           # hidden width not a multiple of 32
     assert sup(4, 4, 4, 128, 768) == 0             # 8-pixel strips do not fit a 4-pixel row
+    assert sup(4, 8, 8, 128, 768) == 0 and sup(8, 4, 4, 256, 1536) == 0      # framed planes of 4 / 8 images: beyond the LDS
     d = L.DecCellDesc()
     d.N, d.H, d.W, d.C, d.Hd = 2, 16, 16, 128, 768
     with pytest.raises(L.GaError):

@@ -103,11 +103,15 @@ def test_assumed_config_plan_matches_survey_flop_count():
     assert n == 24
     eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=1, rep=1, alphas=[0.5] * n,
                  device='cpu', dry_run=True)
+    from bench import dec_cell_algorithmic_flops
     nvae_fwd = sum(2 * (d.N * d.Ho * d.Wo) * d.KH * d.KW * (d.C1 + d.C2) * d.Cout
                    for d, nm in zip(eng.fwd.descs, eng.fwd.names) if isinstance(d, L.ConvDesc) and not nm.startswith('vgg'))
+    assert any(isinstance(d, L.DecCellDesc) for d in eng.fwd.descs)       # the 16 x 16 decoder cells run as fused launches
+    nvae_fwd += dec_cell_algorithmic_flops(eng.fwd)
     assert 13.5e9 < nvae_fwd < 15.2e9, nvae_fwd
     nvae_bwd = sum((2 * (d.N * d.Ho * d.Wo if d.sd == 1 else d.N * d.Hi * d.Wi) * d.KH * d.KW * (d.C1 + d.C2) * d.Cout)
                    for d, nm in zip(eng.bwd.descs, eng.bwd.names) if isinstance(d, L.ConvDesc) and not nm.startswith('vgg'))
+    nvae_bwd += dec_cell_algorithmic_flops(eng.bwd)
     assert 0.9 * nvae_fwd < nvae_bwd < 1.1 * nvae_fwd
     with pytest.raises(RuntimeError):
         eng.forward()
