@@ -34,8 +34,9 @@ dout, ps, pb = torch.randn(N, H, H, Cc, device=dev), torch.rand(N, Cc, device=de
 y, dt1 = torch.empty(N, H, H, Cc, device=dev), torch.empty(N, H, H, Hd, device=dev)
 lib = C.CDLL(os.environ['GA_OPS_LIB']) if os.environ.get('GA_OPS_LIB') else None
 
-FWD = ['store W + barrier', 'issue next W', 'GEMM1', 'SiLU -> P1', 'barrier', 'depthwise', 'SiLU + split -> P2', 'barrier', 'GEMM2', 'barrier']
-BWD = ['store W + barrier', 'GEMM1 + SiLU -> P1, P4', 'barrier', 'depthwise + SiLU\'', 'GEMM3', 'barrier', 'g -> P1 + barrier',
+FWD = ['A depthwise (+ issue next weights)', 'B GEMM1(ch+1) || SiLU + split -> P2', 'barrier 1, W1 / taps -> LDS',
+       'C GEMM2(ch) || SiLU(t1(ch+1)) -> P1', 'barrier 2, W2 -> LDS']
+BWD = ['store W + barrier', 'issue next W, GEMM1, SiLU -> P1, P4', 'barrier', 'depthwise + SiLU\'', 'GEMM3', 'barrier', 'g -> P1 + barrier',
        '* SiLU\'(t2) + barrier', 'depthwise^T + SiLU\' -> HBM', 'barrier']
 
 for backward in (0, 1):
@@ -64,8 +65,9 @@ for backward in (0, 1):
     if lib is not None:
         buf = np.zeros(64, dtype=np.uint64)
         assert lib.ga_debug_dc_trace_read(buf.ctypes.data_as(C.c_void_p), C.c_int(64)) == 0
-        t = buf.reshape(4, 16)[:, :10].astype(np.float64) / (Hd // 32)
+        names = BWD if backward else FWD
+        t = buf.reshape(4, 16)[:, :len(names)].astype(np.float64) / (Hd // 32)
         tot = t.sum(axis=1)
-        for i, nm in enumerate(BWD if backward else FWD):
+        for i, nm in enumerate(names):
             print(f'   {nm:34s} ' + ' '.join(f'{v:8.0f}' for v in t[:, i]) + f'   ({100 * t[:, i].mean() / tot.mean():4.1f} %)')
         print(f'   {"per chunk":34s} ' + ' '.join(f'{v:8.0f}' for v in tot))
