@@ -685,6 +685,23 @@ def main():
                                  'plan) on one stream, right after the timed region'},
             'accuracy_counters': [float(counters[0].item()), float(counters[1].item())],
         }
+        # the second kernel family of the path: the fused decoder cells (ga_dec_cell), per-op HIP events of one chunk
+        from gen_adversarial_amd import _lib as L
+        cell_ms, cell_n = 0.0, 0
+        for plan in (eng.fwd, eng.bwd):
+            for dsc, ms in zip(plan.descs, plan.profile(s)):
+                if isinstance(dsc, L.DecCellDesc):
+                    cell_ms, cell_n = cell_ms + ms, cell_n + 1
+        if cell_n:
+            cfl = dec_cell_algorithmic_flops(eng.fwd) + dec_cell_algorithmic_flops(eng.bwd)
+            out['fused_decoder_cells'] = {
+                'kernel': 'ga::dec_cell_fwd_kernel + ga::dec_cell_bwd_kernel (1x1 expand -> SiLU -> depthwise 5x5 -> SiLU -> 1x1 project, '
+                          'one launch per direction; the 6C-wide tensors stay in LDS / registers)',
+                'launches_per_chunk': cell_n, 'ms_per_chunk': cell_ms, 'avg_launch_ms': cell_ms / cell_n,
+                'algorithmic_gflop_per_chunk': cfl / 1e9, 'achieved_tflops': cfl / (cell_ms / 1e3) / 1e12,
+                'bound': 'vector ALU + LDS of one wave per SIMD (two quarter-rate transcendentals per SiLU, 25 FMAs and 2.7 LDS reads per '
+                         'depthwise output); the contractions are 25 % of its clocks (tools/dec_cell_trace.py)',
+                'share_of_plan_ms': cell_ms / (f_ms + b_ms)}
         if world == 1 and rows_per_step != 256 and not args.no_rows256:
             # SURVEY.md §8(d) words configs[1] as R = 256 defender rows (8 images x EoT 32) in ONE plan run: the same
             # attack step at that size, one engine, one stream, reported beside the headline (never as `value`)

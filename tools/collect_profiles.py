@@ -27,7 +27,7 @@ env = dict(os.environ, TMPDIR='/tmp')
 def family(n):
     return ('ga::conv_bf3_kernel' if 'conv_bf3_kernel' in n else 'ga::conv_halo3_kernel' if 'conv_halo3' in n else
             'ga::conv_mfma_kernel' if 'conv_mfma_kernel' in n else 'ga::conv_splitk_reduce_kernel' if 'splitk' in n else
-            'ga::dwconv5_kernel' if 'dwconv5' in n else 'ga::se_* (excite / apply)' if 'ga::se_' in n else
+            'ga::dec_cell_* (fused decoder cell)' if 'dec_cell' in n else 'ga::dwconv5_kernel' if 'dwconv5' in n else 'ga::se_* (excite / apply)' if 'ga::se_' in n else
             n.split('(')[0].replace('void ', '')[:60])
 
 

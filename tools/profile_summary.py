@@ -14,7 +14,7 @@ for tag, bj, nm in (('s1', b1, '1 stream (kernels run alone: durations comparabl
         n = r['Name']
         key = ('ga::conv_bf3_kernel' if 'conv_bf3_kernel' in n else 'ga::conv_halo3_kernel' if 'conv_halo3' in n else
                'ga::conv_mfma_kernel' if 'conv_mfma_kernel' in n else 'ga::conv_splitk_reduce_kernel' if 'splitk' in n else
-               'ga::dwconv5_kernel' if 'dwconv5' in n else 'ga::se_* (excite / apply)' if 'se_' in n else n.split('(')[0])
+               'ga::dec_cell_* (fused decoder cell)' if 'dec_cell' in n else 'ga::dwconv5_kernel' if 'dwconv5' in n else 'ga::se_* (excite / apply)' if 'se_' in n else n.split('(')[0])
         g = grp.setdefault(key, [0, 0.0])
         g[0] += int(r['Calls'])
         g[1] += float(r['TotalDurationNs'])
