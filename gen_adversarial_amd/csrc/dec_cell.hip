@@ -341,8 +341,8 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
     }
 }
 
-// Backward, per chunk: (a) recompute t1c (GEMM1) -> P4, SiLU -> P1 | (b) depthwise -> SiLU'(t2c) in registers | (c) GEMM3 =
-// dt3 . W2c^T | (d) -> P1 | (e) own strip *= SiLU'(t2c) | (f) depthwise^T, * SiLU'(t1c) -> HBM; a barrier after each.  (The
+// Backward, per chunk: (a) recompute t1c (GEMM1): SiLU' -> P4, SiLU -> P1 | (b) depthwise -> SiLU'(t2c) in registers | (c) GEMM3 =
+// dt3 . W2c^T | (d) -> P1 | (e) own strip *= SiLU'(t2c) | (f) depthwise^T, * P4 -> HBM; a barrier after each.  (The
 // two-GEMMs-beside-VALU pipeline of the forward kernel measured slower here: 8.1 + 6.5 ms against 7.3 + 5.8 ms per 512 rows.)
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
     float* wT = smem + 25 * DC_CH;                                      // [25][32] flipped taps
     float* P1 = smem + 50 * DC_CH;                                      // framed fp32 plane: silu(t1c), later dt2c
     const int plane_px = (M >> gm.lhw) * gm.PH * gm.PW;
-    float* P4 = P1 + plane_px * DC_PS;                                  // [M][DC_PS] t1c (pre-activation)
+    float* P4 = P1 + plane_px * DC_PS;                                  // [M][DC_PS] silu'(t1c)
     __bf16* W1h = reinterpret_cast<__bf16*>(P4 + M * DC_PS);            // the chunk's rows of W1, then of W2^T
     __bf16* W1l = W1h + WA::ELEMS;
     __bf16* W2h = W1l + WA::ELEMS;
@@ -442,8 +442,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
             for (int r = 0; r < 16; ++r) {
                 const int row = wb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const float v = t1[i][r] + b1v;
-                P4[row * DC_PS + lrow] = v;
-                P1[prow[i][r >> 2] + (r & 3) * DC_PS] = silu_f(v);
+                const float sg = fast_sigmoid(v);                       // one sigmoid serves SiLU (now) and SiLU' (step f)
+                P4[row * DC_PS + lrow] = sg * (1.0f + v * (1.0f - sg));
+                P1[prow[i][r >> 2] + (r & 3) * DC_PS] = v * sg;
             }
         DC_T(1)
         __syncthreads();
@@ -491,10 +492,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
 #pragma unroll
             for (int j = 0; j < SW; ++j) {
                 const floatx4 u = *reinterpret_cast<const floatx4*>(P4 + (p0 + j) * DC_PS + 4 * c4);
-                floatx4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = a[j][e] * dsilu_f(u[e]);
-                *reinterpret_cast<floatx4*>(d.y + (pix0 + p0 + j) * d.Hd + h0 + 4 * c4) = o;
+                *reinterpret_cast<floatx4*>(d.y + (pix0 + p0 + j) * d.Hd + h0 + 4 * c4) = a[j] * u;
             }
         }
         DC_T(8)
