@@ -266,29 +266,60 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
         floatx4 a[SW];
         dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
         DC_T(0)
-        // ---- B: GEMM1 of chunk ch + 1  ||  SiLU + split of chunk ch -> P2
+        // ---- B: GEMM1 of chunk ch + 1  ||  SiLU + split of chunk ch -> P2.  One scheduling region per strip pixel: its share of
+        // the k steps (6 / 12 MFMAs, the next region's B-fragments already on their way) beside its ~40 VALU instructions.
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
-        gemm_resident<TMW, KS>(t1, xh, xl, w1h, w1l);
+        {
+            constexpr int KPJ = KS / SW;                // k steps per strip pixel
+            bf16x8 bh[KPJ], bl[KPJ];
 #pragma unroll
-        for (int j = 0; j < SW; ++j) {
-            floatx4 v = a[j] + bd4;
+            for (int k = 0; k < KPJ; ++k) {
+                bh[k] = *reinterpret_cast<const bf16x8*>(w1h + k * 16);
+                bl[k] = *reinterpret_cast<const bf16x8*>(w1l + k * 16);
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-            const bf16x4 hi = __builtin_convertvector(v, bf16x4);
-            const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
-            *reinterpret_cast<bf16x4*>(P2h + (p0 + j) * DC_LDB + 4 * c4) = hi;
-            *reinterpret_cast<bf16x4*>(P2l + (p0 + j) * DC_LDB + 4 * c4) = lo;
+            for (int j = 0; j < SW; ++j) {
+                bf16x8 nh[KPJ], nl[KPJ];
+                if (j + 1 < SW) {
+#pragma unroll
+                    for (int k = 0; k < KPJ; ++k) {
+                        nh[k] = *reinterpret_cast<const bf16x8*>(w1h + ((j + 1) * KPJ + k) * 16);
+                        nl[k] = *reinterpret_cast<const bf16x8*>(w1l + ((j + 1) * KPJ + k) * 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KPJ; ++k)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) {
+                        t1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl[i][j * KPJ + k], bh[k], t1[i], 0, 0, 0);
+                        t1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i][j * KPJ + k], bl[k], t1[i], 0, 0, 0);
+                        t1[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh[i][j * KPJ + k], bh[k], t1[i], 0, 0, 0);
+                    }
+                floatx4 v = a[j] + bd4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
+                *reinterpret_cast<bf16x4*>(P2h + (p0 + j) * DC_LDB + 4 * c4) = hi;
+                *reinterpret_cast<bf16x4*>(P2l + (p0 + j) * DC_LDB + 4 * c4) = lo;
+                interleave_mfma_valu<KPJ * TMW * 3, 42>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < SW) {
+#pragma unroll
+                    for (int k = 0; k < KPJ; ++k) { bh[k] = nh[k]; bl[k] = nl[k]; }
+                }
+            }
         }
-        interleave_mfma_valu<TMW * KS * 3, SW * 4 * 13>();
         DC_T(1)
         __syncthreads();
         wa.store(W1h, W1l, tid);
         if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
         DC_T(2)
-        // ---- C: GEMM2 of chunk ch  ||  SiLU(t1 of chunk ch + 1) -> P1
+        // ---- C: GEMM2 of chunk ch  ||  SiLU(t1 of chunk ch + 1) -> P1.  One scheduling region per (output tile, k step): 6 / 3 MFMAs
+        // beside the SiLU of 4 / 1 accumulator elements.
         {
             bf16x8 ah[TMW][2], al[TMW][2];
 #pragma unroll
@@ -301,25 +332,31 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
                 }
             const __bf16* w2h = W2h + lrow * WB::PITCH + 8 * lh;
             const __bf16* w2l = W2l + lrow * WB::PITCH + 8 * lh;
+            constexpr int NG = 2 * NT, EPG = TMW * 16 / NG;     // regions, accumulator elements per region
+            bf16x8 bh = *reinterpret_cast<const bf16x8*>(w2h), bl = *reinterpret_cast<const bf16x8*>(w2l);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(w2h + j * 32 * WB::PITCH + ks * 16);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(w2l + j * 32 * WB::PITCH + ks * 16);
-#pragma unroll
-                    for (int i = 0; i < TMW; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bl, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bh, acc[i][j], 0, 0, 0);
-                    }
+            for (int g = 0; g < NG; ++g) {
+                const int j = g >> 1, ks = g & 1;
+                bf16x8 nh, nl;
+                if (g + 1 < NG) {
+                    nh = *reinterpret_cast<const bf16x8*>(w2h + ((g + 1) >> 1) * 32 * WB::PITCH + ((g + 1) & 1) * 16);
+                    nl = *reinterpret_cast<const bf16x8*>(w2l + ((g + 1) >> 1) * 32 * WB::PITCH + ((g + 1) & 1) * 16);
                 }
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i][ks], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i][ks], bh, acc[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < EPG; ++e) {
+                    const int idx = g * EPG + e, i = idx >> 4, r = idx & 15;
+                    P1[prow[i][r >> 2] + (r & 3) * DC_PS] = silu_f(t1[i][r] + b1v);
+                }
+                interleave_mfma_valu<TMW * 3, EPG * 9>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 1 < NG) { bh = nh; bl = nl; }
             }
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) P1[prow[i][r >> 2] + (r & 3) * DC_PS] = silu_f(t1[i][r] + b1v);
-            interleave_mfma_valu<TMW * NT * 6, TMW * 16 * 9>();
         }
         DC_T(3)
         __syncthreads();
