@@ -257,11 +257,13 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
     for (int ch = 0; ch < nch; ++ch) {
         const int h0 = ch * DC_CH;
         const int h1 = min(h0 + DC_CH, last), h2 = min(h0 + 2 * DC_CH, last);
+        // the small loads first: a wait on them must not wait on the weight prefetch behind them (vmcnt retires in order)
+        const float b1v = d.b1[h1 + lrow];
+        const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
+        __builtin_amdgcn_sched_barrier(0);
         wa.issue(g1h, g1l, C, h2, tid);
         wq.issue(g2h, g2l, d.Hd, h1, tid);
         taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o + h1);
-        const float b1v = d.b1[h1 + lrow];
-        const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
         // ---- A: depthwise 5x5 of chunk ch
         floatx4 a[SW];
         dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
@@ -379,8 +381,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
 }
 
 // Backward, per chunk: (a) recompute t1c (GEMM1): SiLU' -> P4, SiLU -> P1 | (b) depthwise -> SiLU'(t2c) in registers | (c) GEMM3 =
-// dt3 . W2c^T | (d) -> P1 | (e) own strip *= SiLU'(t2c) | (f) depthwise^T, * P4 -> HBM; a barrier after each.  (The
-// two-GEMMs-beside-VALU pipeline of the forward kernel measured slower here: 8.1 + 6.5 ms against 7.3 + 5.8 ms per 512 rows.)
+// dt3 . W2c^T | (d) -> P1 | (e) own strip *= SiLU'(t2c) | (f) depthwise^T, * P4 -> HBM; a barrier after each.  GEMM3 runs beside
+// SiLU'(t2c) in small scheduling regions.  (A two-GEMMs-beside-VALU software pipeline like the forward kernel's measured 7.75 + 5.29 ms
+// against 7.12 + 5.69 ms per 512 rows for this form: no gain for twice the bookkeeping.)
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
     constexpr int M = 128 * TMW, KS = C / 16, SW = 4 * TMW;
@@ -457,6 +460,10 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         }
         __syncthreads();
         DC_T(0)
+        // the small loads first: a wait on them must not wait on the weight prefetch behind them (vmcnt retires in order)
+        const float b1v = d.b1[h0 + lrow];
+        const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
+        __builtin_amdgcn_sched_barrier(0);
         if (ch + 1 < nch) {
             wa.issue(g1h, g1l, C, h0 + DC_CH, tid);
             wq.issue(g2h, g2l, C, h0 + DC_CH, tid);
@@ -472,7 +479,6 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
 #pragma unroll
             for (int r = 0; r < 16; ++r) t1[i][r] = 0.f;
         gemm_resident<TMW, KS>(t1, xh, xl, W1h + lrow * WA::PITCH + 8 * lh, W1l + lrow * WA::PITCH + 8 * lh);
-        const float b1v = d.b1[h0 + lrow];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -486,24 +492,53 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         DC_T(1)
         __syncthreads();
         DC_T(2)
-        // ---- (b) t2c = dw5(silu(t1c)) + bd  ->  silu'(t2c) in registers
+        // ---- (b) t2c = dw5(silu(t1c)) + bd ;  (c) silu'(t2c) -> registers  ||  g = dt3 . W2c^T, one scheduling region per strip pixel
         floatx4 g2[SW];
-        {
-            dw_strip<SW>(g2, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
-            const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
-#pragma unroll
-            for (int j = 0; j < SW; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) g2[j][e] = dsilu_f(g2[j][e] + bd4[e]);
-        }
+        dw_strip<SW>(g2, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
         DC_T(3)
-        // ---- (c) g = dt3 . W2c^T (after the depthwise pass: its registers are free again)
         floatx16 g[TMW];
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) g[i][r] = 0.f;
-        gemm_resident<TMW, KS>(g, gh, gl, W2h + lrow * WA::PITCH + 8 * lh, W2l + lrow * WA::PITCH + 8 * lh);
+        {
+            const __bf16* w2h = W2h + lrow * WA::PITCH + 8 * lh;
+            const __bf16* w2l = W2l + lrow * WA::PITCH + 8 * lh;
+            constexpr int KPJ = KS / SW;
+            bf16x8 bh[KPJ], bl[KPJ];
+#pragma unroll
+            for (int k = 0; k < KPJ; ++k) {
+                bh[k] = *reinterpret_cast<const bf16x8*>(w2h + k * 16);
+                bl[k] = *reinterpret_cast<const bf16x8*>(w2l + k * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < SW; ++j) {
+                bf16x8 nh[KPJ], nl[KPJ];
+                if (j + 1 < SW) {
+#pragma unroll
+                    for (int k = 0; k < KPJ; ++k) {
+                        nh[k] = *reinterpret_cast<const bf16x8*>(w2h + ((j + 1) * KPJ + k) * 16);
+                        nl[k] = *reinterpret_cast<const bf16x8*>(w2l + ((j + 1) * KPJ + k) * 16);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < KPJ; ++k)
+#pragma unroll
+                    for (int i = 0; i < TMW; ++i) {
+                        g[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gl[i][j * KPJ + k], bh[k], g[i], 0, 0, 0);
+                        g[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[i][j * KPJ + k], bl[k], g[i], 0, 0, 0);
+                        g[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gh[i][j * KPJ + k], bh[k], g[i], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g2[j][e] = dsilu_f(g2[j][e] + bd4[e]);
+                interleave_mfma_valu<KPJ * TMW * 3, 44>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < SW) {
+#pragma unroll
+                    for (int k = 0; k < KPJ; ++k) { bh[k] = nh[k]; bl[k] = nl[k]; }
+                }
+            }
+        }
         DC_T(4)
         __syncthreads();                // every strip is done reading silu(t1c)
         DC_T(5)

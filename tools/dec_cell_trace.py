@@ -36,8 +36,8 @@ lib = C.CDLL(os.environ['GA_OPS_LIB']) if os.environ.get('GA_OPS_LIB') else None
 
 FWD = ['A depthwise (+ issue next weights)', 'B GEMM1(ch+1) || SiLU + split -> P2', 'barrier 1, W1 / taps -> LDS',
        'C GEMM2(ch) || SiLU(t1(ch+1)) -> P1', 'barrier 2, W2 -> LDS']
-BWD = ['store W + barrier', 'issue next W, GEMM1, SiLU -> P1, P4', 'barrier', 'depthwise + SiLU\'', 'GEMM3', 'barrier', 'g -> P1 + barrier',
-       '* SiLU\'(t2) + barrier', 'depthwise^T + SiLU\' -> HBM', 'barrier']
+BWD = ['weights / taps -> LDS, barrier', 'issue next weights, GEMM1, SiLU / SiLU\' -> P1, P4', 'barrier', 'depthwise', 'SiLU\'(t2) || GEMM3', 'barrier',
+       'g -> P1, barrier', '* SiLU\'(t2), barrier', 'depthwise^T, * P4 -> HBM', 'barrier']
 
 for backward in (0, 1):
     d = L.DecCellDesc()
