@@ -38,6 +38,10 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
     # decoder cells whose shape ga_dec_cell takes run as one fused launch per direction (GA_FUSE_DEC_CELL=0: the three
     # unfused launches, same numbers bit for bit — kept for A/B profiles and for the shapes the fused kernel refuses)
     fuse_dec_cells = os.environ.get('GA_FUSE_DEC_CELL', '1') != '0'
+    # ... and only when the launch fills the chip: a fused workgroup walks the hidden width serially (115 us at 128 channels, 220 us at
+    # 256, whatever the row count up to 256 workgroups), the three unfused launches scale with the rows: below ~160 workgroups they win
+    # (the reference protocol of one image x EoT 32 would pay 10 ms of a 21 ms step).  GA_FUSE_DEC_CELL=force: always (tests).
+    fuse_min_workgroups = 0 if os.environ.get('GA_FUSE_DEC_CELL') == 'force' else 160
 
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,

@@ -64,8 +64,9 @@ class NvaeBuilder:
         hid_c = cell.hidden
         p = cell.prefix
         # whole-image tiles at 128 / 256 channels: ONE launch per direction, the two hid_c-wide tensors never reach HBM
-        fused = (not up and self.precision == 'bf16x3' and self.fuse_dec_cells
-                 and L.lib.ga_dec_cell_supported(n, H, W, x.c, hid_c) == 1 and cell.cout == x.c)
+        fused = (not up and self.precision == 'bf16x3' and self.fuse_dec_cells and cell.cout == x.c
+                 and L.lib.ga_dec_cell_supported(n, H, W, x.c, hid_c) == 1
+                 and n * H * W // (256 if x.c == 128 else 128) >= self.fuse_min_workgroups)
         t3 = Act(self, n, H, W, cell.cout, p + '.t3')
         out = Act(self, n, H, W, cell.cout, p + '.out')
 

@@ -191,3 +191,35 @@ def test_fullsize_properties(model):
     rel = ((analytic - numeric).abs() / numeric.abs()).max().item()
     print(f'directional derivative: analytic {analytic.tolist()} numeric {numeric.tolist()} rel {rel:.2e}')
     assert rel < 3e-2
+
+
+def test_fused_decoder_cells_equal_the_unfused_launches_bitwise(model, monkeypatch):
+    """The 32 decoder cells at 16 x 16 x 128 and 8 x 8 x 256 as ga_dec_cell launches (forced: an 8-row plan is far below the
+    workgroup count from which the engine picks them) against the same plan built from the three launches per direction the
+    fused kernel replaces: same operand split, k order and depthwise loop order => bitwise equal image, logits and input gradient."""
+    from gen_adversarial_amd import _lib as L
+    m, spec = model, model['spec']
+    rows, rep = 8, 2
+    gen = torch.Generator().manual_seed(21)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    dlog = torch.randn(rows, 100, generator=gen)
+    out = []
+    for fuse, min_wgs in ((False, 160), (True, 0), (True, 160)):
+        monkeypatch.setattr(Engine, 'fuse_dec_cells', fuse)
+        monkeypatch.setattr(Engine, 'fuse_min_workgroups', min_wgs)
+        eng = engine(m, rows, rep)
+        n_fused = sum(isinstance(d, L.DecCellDesc) for d in eng.fwd.descs), sum(isinstance(d, L.DecCellDesc) for d in eng.bwd.descs)
+        assert n_fused == ((32, 32) if fuse and min_wgs == 0 else (0, 0)), n_fused      # 8 rows: fused only when forced
+        eng.x_in.copy_(imgs.to(DEV))
+        for dst, src in zip(eng.eps, eps):
+            dst.copy_(src.to(DEV))
+        eng.forward()
+        eng.dlogits.view(rows, -1).copy_(dlog.to(DEV))
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append((eng.purified.clone(), eng.logits.clone(), eng.dx.clone(), eng.bytes))
+        del eng
+    (p0, l0, g0, b0), (p1, l1, g1, b1), _ = out
+    assert torch.equal(p0, p1) and torch.equal(l0, l1) and torch.equal(g0, g1)
+    assert b1 < 0.75 * b0          # the two 6C-wide tensors of those cells are no longer stored

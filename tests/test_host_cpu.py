@@ -92,7 +92,7 @@ def _flops(plan):
     return tot
 
 
-def test_assumed_config_plan_matches_survey_flop_count():
+def test_assumed_config_plan_matches_survey_flop_count(monkeypatch):
     """15.15 GFLOP/row forward for the assumed NVAE config (we skip the unused log-sigma half of the
     encoder samplers, apply the up-cell 1x1 convs before upsampling and fold the prior half of combiner_0:0,
     so the plan is slightly BELOW the reference's count)."""
@@ -101,6 +101,10 @@ def test_assumed_config_plan_matches_survey_flop_count():
     sd = init_nvae_state_dict(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, 0)
     n = len(build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION).groups)
     assert n == 24
+    eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=1, rep=1, alphas=[0.5] * n,
+                 device='cpu', dry_run=True)
+    assert not any(isinstance(d, L.DecCellDesc) for d in eng.fwd.descs)   # one row: the fused cell would leave 255 CUs idle
+    monkeypatch.setattr(Engine, 'fuse_min_workgroups', 0)
     eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=1, rep=1, alphas=[0.5] * n,
                  device='cpu', dry_run=True)
     from bench import dec_cell_algorithmic_flops
