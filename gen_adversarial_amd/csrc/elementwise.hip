@@ -284,6 +284,7 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % d.NL); const long pix = i / d.NL;            // pix = n*hw + p
         const int n = (int)(pix / hw), p = (int)(pix % hw);
+        const long zi = d.ldz > 0 ? pix * d.ldz + c : i;
         const long qpix = d.q_rep > 1 ? (long)(n / d.q_rep) * hw + p : pix;
         const float mq = d.mu_q[qpix * d.ldq + c];
         const float mp = d.p ? d.p[pix * d.ldp + c] : 0.f;
@@ -294,11 +295,11 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
         if (!d.backward) {
             const float enc_mu = softclamp5(mp + mq);
             const float smp = e * sig + softclamp5(mp);
-            d.z[i] = om * enc_mu + a * smp;
+            d.z[zi] = om * enc_mu + a * smp;
         } else {
-            const float dz = d.dz[i];
+            const float dz = d.dz[zi];
             const float denc = om * dz * dsoftclamp5(mp + mq);
-            if (d.q_rep > 1) d.dmu_q_rows[i] = denc; else d.dmu_q[pix * d.ldq + c] = denc;
+            if (d.q_rep > 1) d.dmu_q_rows[d.ldz > 0 ? pix * d.ldq + c : i] = denc; else d.dmu_q[pix * d.ldq + c] = denc;
             if (d.dp) {
                 d.dp[pix * d.ldp + c] = denc + a * dz * dsoftclamp5(mp);
                 d.dp[pix * d.ldp + d.NL + c] = a * dz * e * sig * dsoftclamp5(ls);

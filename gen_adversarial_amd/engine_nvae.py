@@ -136,6 +136,7 @@ class NvaeBuilder:
         spec, R = self.spec, self.rows
         H = spec.resolution
         NL = spec.num_latent
+        self.latent_pitch = (NL + 7) // 8 * 8
         self.eps = [self.alloc((R, NL, gs.res, gs.res)) for gs in spec.groups]   # NCHW like the reference draws them
         self.purified = self.alloc((R, 3, H, H))                            # NCHW
 
@@ -172,10 +173,14 @@ class NvaeBuilder:
         enc0 = self.devd('encoder_0', lambda: F.fold_wn_conv(nvae_sd, 'encoder_0.1'))
         e0 = Act(self, RE, g0.res, g0.res, C0, 'enc0')
         self.conv(self.fwd, 'encoder_0', x_top.t, enc0['w'], e0.t, bias=enc0['b'], K=1, pro_act=L.GA_ACT_ELU)
-        s00 = self.devd('enc_sampler_0:0', lambda: F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)))
-        muq0 = Act(self, RE, g0.res, g0.res, NL, 'mu_q0')
+        # latent tensors (mu_q, z and their cotangents) carry NLP = NL rounded up to 8 channels, the extra ones exact zeros meeting
+        # zero weights: a conv with 20 input channels runs on the exact-fp32 kernel, with 24 on the split-bf16 ones
+        NLP = self.latent_pitch
+        s00 = self.devd('enc_sampler_0:0', lambda: F.pad_conv_out(
+            F.fold_wn_conv(nvae_sd, 'enc_sampler.sampler_0:0', out_slice=slice(0, NL)), NL, NLP))
+        muq0 = Act(self, RE, g0.res, g0.res, NLP, 'mu_q0')
         self.conv(self.fwd, 'enc_sampler_0:0', e0.t, s00['w'], muq0.t, bias=s00['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
-        z = Act(self, R, g0.res, g0.res, NL, 'z0')
+        z = Act(self, R, g0.res, g0.res, NLP, 'z0')
         self._sampler_fwd('sample_0:0', muq0, None, self.eps[0], z, self.alphas[0], q_rep=erep)
 
         # ---- combiner_0:0 on cat[const_prior, z0]: the prior half is row-independent -> folded into a broadcast addend
@@ -186,7 +191,8 @@ class NvaeBuilder:
                 nvae_sd['decoder_combiners.combiner_0:0.conv.bias'].double()
             if spec.num_nf_cells:            # flow of this group = z - c (folding.nf_constant_shift): fold W_z c into the addend
                 pc = pc - wfull[:, C0:] @ F.nf_constant_shift(nvae_sd, '0:0', spec.num_nf_cells, NL)
-            return {'pc': pc.float().unsqueeze(0), 'wz': wfull[:, C0:].float(), 'wz_bwd': wfull[:, C0:].t().float()}
+            return {'pc': pc.float().unsqueeze(0), 'wz': F.pad_cols(wfull[:, C0:].float(), 0, NL, NLP),
+                    'wz_bwd': F.pad_rows(wfull[:, C0:].t().float().contiguous(), NLP)}
         c0w = self.devd('combiner_0:0', fold_comb0)
         pc, wz, wz_bwd = c0w['pc'], c0w['wz'], c0w['wz_bwd']                                     # pc: [1,h,w,C0]
         x = Act(self, R, g0.res, g0.res, C0, 'comb_0:0')
@@ -216,13 +222,14 @@ class NvaeBuilder:
             x = self.dec_cell(cell, x)
 
         # ---- to_logits (ELU -> 3x3, model.py:310-313) + DiscMixLogistic.mean + denormalise
-        tl = self.devd('to_logits', lambda: F.fold_wn_conv(nvae_sd, 'to_logits.1'))
-        logits = Act(self, R, H, H, spec.logits_out, 'mix_logits')
+        LO = (spec.logits_out + 7) // 8 * 8          # channel pitch of the mixture logits: the transposed conv then takes the bf16 path
+        tl = self.devd('to_logits', lambda: F.pad_conv_out(F.fold_wn_conv(nvae_sd, 'to_logits.1'), spec.logits_out, LO))
+        logits = Act(self, R, H, H, LO, 'mix_logits')
         post_out = x
         self.conv(self.fwd, 'to_logits', x.t, tl['w'], logits.t, bias=tl['b'], K=3, pad=1, pro_act=L.GA_ACT_ELU)
         img = Act(self, R, H, H, IMG_LD, 'purified_nhwc')
         dm = L.DmlDesc()
-        dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
+        dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), LO, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
         dm.N, dm.H, dm.W, dm.backward, dm.ld_img = R, H, H, 0, IMG_LD
         self.fwd.add(dm, 'dml_mean')
         self.dpurified = self.alloc((R, 3, H, H))    # optional external gradient on the purified image (NCHW)
@@ -230,7 +237,7 @@ class NvaeBuilder:
 
         def bwd_dml():
             b = L.DmlDesc()
-            b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), spec.logits_out, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
+            b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), LO, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
             b.dimg_nchw = _ptr(self.dpurified)
             b.N, b.H, b.W, b.backward, b.ld_img = R, H, H, 1, IMG_LD
             self.bwd.add(b, 'dml_mean^T')
@@ -247,7 +254,7 @@ class NvaeBuilder:
         if p is not None:
             d.p, d.ldp = _ptr(p.t), p.c
         d.eps, d.eps_nchw, d.z = _ptr(eps), 1, _ptr(z.t)
-        d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
+        d.N, d.h, d.w, d.NL, d.ldz = z.n, z.h, z.w, self.spec.num_latent, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 0
         d.q_rep = q_rep
         self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
@@ -267,7 +274,7 @@ class NvaeBuilder:
             d.dmu_q_rows = _ptr(rows_grad)
         else:
             d.dmu_q = _ptr(muq.g)
-        d.N, d.h, d.w, d.NL = z.n, z.h, z.w, z.c
+        d.N, d.h, d.w, d.NL, d.ldz = z.n, z.h, z.w, self.spec.num_latent, z.c
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 1
         self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.bwd.add(d, name)
@@ -288,7 +295,9 @@ class NvaeBuilder:
         sd, R, NL, C, r = self.nvae_sd, self.rows, self.spec.num_latent, gs.channels, gs.res
         key = f'{gs.s}:{gs.g}'
         ec_w = self.devd(f'enc_combiner_{key}', lambda: F.fold_wn_conv(sd, f'encoder_combiners.combiner_{key}.conv'))
-        es_w = self.devd(f'enc_sampler_{key}', lambda: F.fold_wn_conv(sd, f'enc_sampler.sampler_{key}', out_slice=slice(0, NL)))
+        NLP = self.latent_pitch
+        es_w = self.devd(f'enc_sampler_{key}', lambda: F.pad_conv_out(
+            F.fold_wn_conv(sd, f'enc_sampler.sampler_{key}', out_slice=slice(0, NL)), NL, NLP))
         ds_w = self.devd(f'dec_sampler_{key}', lambda: F.fold_wn_conv(sd, f'dec_sampler.sampler_{key}.1'))
 
         def fold_comb():
@@ -296,8 +305,8 @@ class NvaeBuilder:
             bias = sd[f'decoder_combiners.combiner_{key}.conv.bias'].double()
             if self.spec.num_nf_cells:       # the group's flow is z - c: combiner(cat[x, z - c]) = ... - W_z c
                 bias = bias - cb[:, C:] @ F.nf_constant_shift(sd, key, self.spec.num_nf_cells, NL)
-            return {'w': cb.float(), 'b': bias.float(),
-                    'x_bwd': cb[:, :C].t().float(), 'z_bwd': cb[:, C:].t().float()}
+            return {'w': F.pad_cols(cb.float(), C, NL, NLP), 'b': bias.float(),
+                    'x_bwd': cb[:, :C].t().float(), 'z_bwd': F.pad_rows(cb[:, C:].t().float().contiguous(), NLP)}
         cbw = self.devd(f'combiner_{key}', fold_comb)
         cb_w, cb_b, cbx_bwd, cbz_bwd = cbw['w'], cbw['b'], cbw['x_bwd'], cbw['z_bwd']
         alpha = self.alphas[gs.latent_idx]
@@ -306,11 +315,11 @@ class NvaeBuilder:
         ec = Act(self, R, r, r, C, f'ec_{key}')
         d_ec = self.conv(self.fwd, f'enc_combiner_{key}', x.t, ec_w['w'], ec.t, bias=ec_w['b'], K=1, addend=enc_feat.t)
         d_ec.addend_rep = enc_rep
-        muq = Act(self, R, r, r, NL, f'mu_q_{key}')
+        muq = Act(self, R, r, r, NLP, f'mu_q_{key}')
         self.conv(self.fwd, f'enc_sampler_{key}', ec.t, es_w['w'], muq.t, bias=es_w['b'], K=3, pad=1)
         pp = Act(self, R, r, r, 2 * NL, f'p_{key}')
         self.conv(self.fwd, f'dec_sampler_{key}', x.t, ds_w['w'], pp.t, bias=ds_w['b'], K=1, pro_act=L.GA_ACT_ELU)
-        z = Act(self, R, r, r, NL, f'z_{key}')
+        z = Act(self, R, r, r, NLP, f'z_{key}')
         self._sampler_fwd(f'sample_{key}', muq, pp, eps, z, alpha)
         out = Act(self, R, r, r, C, f'comb_{key}')
         self.conv(self.fwd, f'combiner_{key}', x.t, cb_w, out.t, bias=cb_b, K=1, x2=z.t)

@@ -179,7 +179,7 @@ typedef struct ga_sampler_desc {
     const float* mu_q; int ldq;
     const float* p;    int ldp;
     const float* eps;  int eps_nchw;
-    float* z;          /* fwd out [N,h,w,NL] */
+    float* z;          /* fwd out [N,h,w,ldz] channels [0,NL) */
     const float* dz;   /* bwd in */
     float* dmu_q; float* dp;   /* bwd out */
     int N, h, w, NL; float alpha, one_minus_alpha, temp; int backward;   /* one_minus_alpha = (float)(1.0 - alpha_double) */
@@ -187,6 +187,9 @@ typedef struct ga_sampler_desc {
                           NOT written (several rows map to one): the caller gets d(mu_q) per row in `dmu_q_rows` [N,h,w,NL]
                           and reduces it with ga_rep_sum */
     float* dmu_q_rows;
+    int ldz;           /* channel pitch of z and dz (0: NL).  Latent tensors padded to a multiple of 8 channels (zeros) keep the convs
+                          around them on the split-bf16 kernels; dmu_q_rows then has pitch ldq like dmu_q */
+    int _reserved;
 } ga_sampler_desc;
 int ga_sampler_mix(const ga_sampler_desc* d, void* stream);
 

@@ -264,15 +264,21 @@ def test_robust_accuracy_delta_vs_oracle_under_pgd(precision):
         xo = xa_o.clone().requires_grad_(True)
         loss = torch.nn.functional.cross_entropy(oracle_logits(xo, draws[1 + s]), labels, reduction='sum')
         (g_o,) = torch.autograd.grad(loss, [xo])
-        lh = hip_logits(xa_h, draws[1 + s])
-        p = torch.softmax(lh, dim=1)
-        p[torch.arange(B), labels.to(DEV)] -= 1.0
-        eng.dlogits.view(B, eot, -1).copy_((p / eot).unsqueeze(1).expand(-1, eot, -1))
-        eng.backward()
-        g_h = eng.dx.cpu()
-        # compare raw gradients where the sign is not on a knife edge, then take the same kind of step on each path
-        rel = (g_h - g_o).abs().max().item() / max(g_o.abs().max().item(), 1e-12)
-        assert rel < 5e-2, rel                                    # max-pool near-ties can move isolated elements
+        def hip_grad(x):
+            lh = hip_logits(x, draws[1 + s])
+            p = torch.softmax(lh, dim=1)
+            p[torch.arange(B), labels.to(DEV)] -= 1.0
+            eng.dlogits.view(B, eot, -1).copy_((p / eot).unsqueeze(1).expand(-1, eot, -1))
+            eng.backward()
+            return eng.dx.cpu()
+        # gradients are compared at the SAME point (the oracle's iterate; the two trajectories drift apart wherever a gradient sign
+        # sits on a knife edge).  Max-pool near-ties can move isolated elements (a flipped window moves one entry to its neighbour,
+        # whatever the size of the rounding difference that flipped it): the bulk in relative L2, the worst element only bounded
+        g_same = hip_grad(xa_o)
+        rel_l2 = ((g_same - g_o).norm() / g_o.norm()).item()
+        rel_max = (g_same - g_o).abs().max().item() / max(g_o.abs().max().item(), 1e-12)
+        assert rel_l2 < 5e-2 and rel_max < 0.5, (s, rel_l2, rel_max)
+        g_h = hip_grad(xa_h)                                        # the HIP path's own trajectory
         xa_o = torch.min(torch.max(xa_o + alpha * g_o.sign(), x0 - eps_ball), x0 + eps_ball).clamp(0, 1)
         xa_h = torch.min(torch.max(xa_h + alpha * g_h.sign(), x0 - eps_ball), x0 + eps_ball).clamp(0, 1)
     with torch.no_grad():

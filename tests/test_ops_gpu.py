@@ -523,9 +523,12 @@ def test_bilinear_skip(N, h, Cc):
     close(nchw(dl), gl, 1e-6, 'bilinear bwd')
 
 
-@pytest.mark.parametrize('first', [True, False])
-def test_sampler(first):
+@pytest.mark.parametrize('first,pitch', [(True, 0), (False, 0), (True, 8), (False, 8)])
+def test_sampler(first, pitch):
+    """pitch > 0: mu_q, z and their cotangents carry `pitch` channels per pixel (the engine pads the 20 latent channels to 24 with
+    zeros); the pad channels are neither read nor written"""
     N, h, NL, alpha, temp = 3, 4, 6, 0.35, 0.6
+    LD = pitch or NL
     mq = g(N, NL, h, h, seed=1, scale=3)
     p = None if first else g(N, 2 * NL, h, h, seed=2, scale=3)
     eps = g(N, NL, h, h, seed=3)
@@ -534,28 +537,44 @@ def test_sampler(first):
     sc = lambda v: torch.tanh(v / 5.0) * 5.0
     mp, ls = (torch.zeros_like(mq), torch.zeros_like(mq)) if first else (pr[:, :NL], pr[:, NL:])
     ref = (1 - alpha) * sc(mp + mqr) + alpha * (eps * (temp * torch.exp(sc(ls))) + sc(mp))
-    z = torch.empty(N, h, h, NL, device=DEV)
+
+    def padded(t):          # NCHW cpu -> NHWC gpu with LD channels, the pad ones poisoned
+        out = torch.full((N, h, h, LD), 7.0, device=DEV)
+        out[..., :NL] = nhwc(t)
+        return out
+    z = torch.full((N, h, h, LD), -3.0, device=DEV)
     d = L.SamplerDesc()
-    mqd, ed = nhwc(mq), eps.to(DEV)
+    mqd, ed = padded(mq), eps.to(DEV)
     pd = None if first else nhwc(p)
-    d.mu_q, d.ldq, d.eps, d.eps_nchw, d.z = mqd.data_ptr(), NL, ed.data_ptr(), 1, z.data_ptr()
+    d.mu_q, d.ldq, d.eps, d.eps_nchw, d.z, d.ldz = mqd.data_ptr(), LD, ed.data_ptr(), 1, z.data_ptr(), pitch
     if not first:
         d.p, d.ldp = pd.data_ptr(), 2 * NL
     d.N, d.h, d.w, d.NL, d.alpha, d.one_minus_alpha, d.temp = N, h, h, NL, alpha, 1 - alpha, temp
     L.run(d)
-    close(nchw(z), ref, 1e-6, 'sampler fwd')
+    close(nchw(z[..., :NL]), ref, 1e-6, 'sampler fwd')
+    assert bool((z[..., NL:] == -3.0).all())
     cot = g(*ref.shape, seed=4)
     grads = torch.autograd.grad((ref * cot).sum(), [mqr] if first else [mqr, pr])
-    dmq = torch.empty(N, h, h, NL, device=DEV)
+    dmq = torch.full((N, h, h, LD), -5.0, device=DEV)
     dp = torch.empty(N, h, h, 2 * NL, device=DEV)
-    cd = nhwc(cot)
+    cd = padded(cot)
     d.backward, d.dz, d.dmu_q = 1, cd.data_ptr(), dmq.data_ptr()
     if not first:
         d.dp = dp.data_ptr()
     L.run(d)
-    close(nchw(dmq), grads[0], 1e-6, 'sampler dmu_q')
+    close(nchw(dmq[..., :NL]), grads[0], 1e-6, 'sampler dmu_q')
+    assert bool((dmq[..., NL:] == -5.0).all())
     if not first:
         close(nchw(dp), grads[1], 1e-6, 'sampler dp')
+    if pitch:               # replicas sharing mu_q: per-row gradients with the same pitch
+        rows = torch.full((N, h, h, LD), -9.0, device=DEV)
+        d.q_rep, d.dmu_q, d.dmu_q_rows = 1, dmq.data_ptr(), rows.data_ptr()
+        d.q_rep = 3 if N % 3 == 0 else 1
+        mq1 = padded(mq[:N // d.q_rep])
+        d.mu_q = mq1.data_ptr()
+        L.run(d)
+        torch.cuda.synchronize()
+        assert bool((rows[..., NL:] == -9.0).all()) and torch.isfinite(rows[..., :NL]).all()
 
 
 def test_dml_mean():
