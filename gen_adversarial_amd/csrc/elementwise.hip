@@ -90,6 +90,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
             const float* a = d.t + (size_t)n * d.P * d.C + 4 * q;
             const float* b = d.backward ? d.dout + (size_t)n * d.P * d.C + 4 * q : nullptr;
+#pragma unroll 8
             for (int p = pl; p < d.P; p += PL) {
                 floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
                 if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
                 float acc = 0.f;
                 const int q0 = ch * per, q1 = min(C4, q0 + per);
                 if ((d.C & 3) == 0) {
+#pragma unroll 8
                     for (int q = q0; q < q1; ++q) {
                         const floatx4 w = *reinterpret_cast<const floatx4*>(d.w1 + (size_t)j * d.C + 4 * q);
                         const floatx4 v = *reinterpret_cast<const floatx4*>(s_in + 4 * q);
@@ -149,6 +151,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             float acc = d.b2[c];
             const float* w = d.w2 + (size_t)c * d.Hd;
             if ((d.Hd & 3) == 0) {
+#pragma unroll 8
                 for (int j = 0; j < d.Hd; j += 4) {
                     const floatx4 wv = *reinterpret_cast<const floatx4*>(w + j);
                     acc += wv[0] * fmaxf(s_hid[j], 0.f) + wv[1] * fmaxf(s_hid[j + 1], 0.f) +
@@ -172,6 +175,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
         if (256 % d.Hd == 0) {
             const int j = tid % d.Hd, nch = 256 / d.Hd, ch = tid / d.Hd;
             float acc = 0.f;
+#pragma unroll 16
             for (int c = ch; c < d.C; c += nch) acc += d.w2[(size_t)c * d.Hd + j] * s_in[c];
             s_red[j * nch + ch] = acc;
             __syncthreads();
@@ -191,6 +195,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
         const float invP = 1.0f / (float)d.P;
         for (int c = tid; c < d.C; c += 256) {
             float acc = 0.f;
+#pragma unroll 16
             for (int j = 0; j < d.Hd; ++j) acc += d.w1[(size_t)j * d.C + c] * s_hid[j];
             d.pro_scale[(size_t)n * d.C + c] = d.res_scale * d.gate[(size_t)n * d.C + c];
             d.pro_shift[(size_t)n * d.C + c] = acc * invP;
