@@ -330,9 +330,21 @@ __global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, cons
     for (long base = (long)blockIdx.x * DML_ROWS; base < npix; base += (long)gridDim.x * DML_ROWS) {
         const int nrow = (int)min((long)DML_ROWS, npix - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
-            const int r = k / d.ld, c = k - r * d.ld;
-            dml_s[r * pitch + c] = d.logits[base * d.ld + k];
+        if ((d.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(d.logits) & 15) == 0) {   // 16-B global accesses (a quad never straddles two pixels)
+            const floatx4* src = reinterpret_cast<const floatx4*>(d.logits + base * d.ld);
+            const int ld4 = d.ld >> 2;
+#pragma unroll 4
+            for (int k = threadIdx.x; k < nrow * ld4; k += DML_ROWS) {
+                const int r = k / ld4, c = 4 * (k - r * ld4);
+                const floatx4 v = src[k];
+                float* o = dml_s + r * pitch + c;
+                o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3];
+            }
+        } else {
+            for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
+                const int r = k / d.ld, c = k - r * d.ld;
+                dml_s[r * pitch + c] = d.logits[base * d.ld + k];
+            }
         }
         __syncthreads();
         const long i = base + threadIdx.x;
@@ -397,9 +409,21 @@ __global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, cons
         }   // active
         if (d.backward) {
             __syncthreads();
-            for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
-                const int r = k / d.ld, c = k - r * d.ld;
-                d.dlogits[base * d.ld + k] = dml_s[r * pitch + c];
+            if ((d.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(d.dlogits) & 15) == 0) {
+                floatx4* dst = reinterpret_cast<floatx4*>(d.dlogits + base * d.ld);
+                const int ld4 = d.ld >> 2;
+#pragma unroll 4
+                for (int k = threadIdx.x; k < nrow * ld4; k += DML_ROWS) {
+                    const int r = k / ld4, c = 4 * (k - r * ld4);
+                    const float* o = dml_s + r * pitch + c;
+                    const floatx4 v = {o[0], o[1], o[2], o[3]};
+                    dst[k] = v;
+                }
+            } else {
+                for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
+                    const int r = k / d.ld, c = k - r * d.ld;
+                    d.dlogits[base * d.ld + k] = dml_s[r * pitch + c];
+                }
             }
         }
     }
