@@ -153,6 +153,90 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
     }
 }
 
+// 4 x 4 images (the deepest decoder cells: 512 rows x 3072 channels = 12288 workgroups of 16 KB each in the windowed form, 88 us
+// of mostly workgroup turnover): no halo frame — 16 images x 16 pixels x 32 channels in 32 KB of LDS, the border handled by
+// the loop bounds (a 4 x 4 image meets 9 - 16 of the 25 taps per output, the others are skipped, not multiplied by zero).
+// Work item = (image, output row, channel quad): four outputs from at most four input rows.
+__global__ void __launch_bounds__(256, 4) dwconv5_4x4_kernel(const ga_dwconv5_desc d, const int nchunks) {
+    constexpr int NB = 16;
+    __shared__ __attribute__((aligned(16))) float wS[25 * DW_CC];
+    __shared__ __attribute__((aligned(16))) float tile[NB * 16 * DW_CC];
+    const int tid = threadIdx.x, c4 = tid & 7, pl = tid >> 3;
+    const int chunk = blockIdx.x % nchunks;
+    const int n0 = (blockIdx.x / nchunks) * NB;
+    const int nb = min(NB, d.N - n0);
+    const int c = chunk * DW_CC + 4 * c4;
+    const bool cok = c < d.C;
+    const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 200) {
+        const int t = tid >> 3;
+        *reinterpret_cast<floatx4*>(wS + t * DW_CC + 4 * c4) = cok ? *reinterpret_cast<const floatx4*>(d.w + (size_t)t * d.C + c) : zero;
+    }
+    floatx4 bias = zero;
+    if (cok && d.bias) bias = *reinterpret_cast<const floatx4*>(d.bias + c);
+    // ---- stage nb * 16 pixels: 8 loads per thread, all issued before the first use
+    {
+        floatx4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pl + 32 * k;
+            const bool ok = cok && p < nb * 16;
+            v[k] = ok ? *reinterpret_cast<const floatx4*>(d.x + ((size_t)n0 * 16 + p) * d.C + c) : zero;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int p = pl + 32 * k;
+            floatx4 o = v[k];
+            if (d.pro_act == GA_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] * fast_sigmoid(o[e]);
+            } else if (d.pro_act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act_fwd_fast(o[e], d.pro_act);
+            }
+            *reinterpret_cast<floatx4*>(tile + p * DW_CC + 4 * c4) = o;
+        }
+    }
+    __syncthreads();
+    if (!cok) return;
+    for (int s = pl; s < nb * 4; s += 32) {
+        const int ni = s >> 2, h = s & 3;
+        floatx4 acc[4] = {bias, bias, bias, bias};
+        const int kh0 = max(0, 2 - h), kh1 = min(5, 6 - h);          // input row h + kh - 2 inside [0, 4)
+        for (int kh = kh0; kh < kh1; ++kh) {
+            const float* row = tile + ((ni * 4 + h + kh - 2) * 4) * DW_CC + 4 * c4;
+            floatx4 in[4], w5[5];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) in[j] = *reinterpret_cast<const floatx4*>(row + j * DW_CC);
+#pragma unroll
+            for (int kw = 0; kw < 5; ++kw) w5[kw] = *reinterpret_cast<const floatx4*>(wS + (kh * 5 + kw) * DW_CC + 4 * c4);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kw = j - w + 2;                       // compile-time after unrolling
+                    if (kw >= 0 && kw < 5) acc[w] += in[j] * w5[kw];
+                }
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const size_t o = (((size_t)(n0 + ni) * 4 + h) * 4 + w) * d.C + c;
+            floatx4 v = acc[w];
+            if (d.dact_x) {
+                const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
+                if (d.dact_act == GA_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(u[e]); v[e] *= sg * (1.0f + u[e] * (1.0f - sg)); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_bwd_fast(u[e], d.dact_act);
+                }
+            }
+            *reinterpret_cast<floatx4*>(d.y + o) = v;
+        }
+    }
+}
+
 }  // namespace ga
 
 extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
@@ -168,6 +252,13 @@ extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
         (d.dact_x && !aligned16(d.dact_x))) return GA_E_ALIGN;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 
+    if (d.H == 4 && d.W == 4 && !d.up2 && !d.pool2) {
+        const int nchunks = (d.C + DW_CC - 1) / DW_CC;
+        const long blocks = (long)((d.N + 15) / 16) * nchunks;
+        if (blocks > 0x7fffffffL) return GA_E_UNSUPPORTED;
+        hipLaunchKernelGGL(dwconv5_4x4_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d, nchunks);
+        return check_launch();
+    }
     // 8 x 16 output windows: (12 x 20) x 32 ch halo = 30 KB of LDS -> 4 workgroups per CU
     const int TH = d.H < 8 ? d.H : 8, TW = d.W < 16 ? d.W : 16;
     const int halo_bytes = (TH + 4) * (TW + 4) * DW_CC * 4;

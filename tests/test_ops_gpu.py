@@ -407,7 +407,7 @@ def test_conv_rejects_bad_descriptors():
         L.run(d)
 
 
-@pytest.mark.parametrize('N,H,Cc,up', [(5, 4, 48, False), (3, 8, 96, False), (2, 16, 32, False), (2, 32, 12, False),
+@pytest.mark.parametrize('N,H,Cc,up', [(5, 4, 48, False), (37, 4, 100, False), (3, 8, 96, False), (2, 16, 32, False), (2, 32, 12, False),
                                        (3, 8, 48, True), (2, 40, 8, True), (9, 4, 36, True)])
 def test_dwconv5(N, H, Cc, up):
     hs = H // 2 if up else H
