@@ -464,13 +464,14 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         const float b1v = d.b1[h0 + lrow];
         const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
         __builtin_amdgcn_sched_barrier(0);
-        if (ch + 1 < nch) {
-            wa.issue(g1h, g1l, C, h0 + DC_CH, tid);
-            wq.issue(g2h, g2l, C, h0 + DC_CH, tid);
-            if (tid < 200) {
-                taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + h0 + DC_CH + 4 * c4);
-                tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + h0 + DC_CH + 4 * c4);
-            }
+        {   // straight-line code (the last chunk prefetches itself again): behind a branch the compiler can no longer count the
+            // loads in flight and waits for ALL of them at the first use of b1v — 3 K clocks per chunk
+            const int h1 = min(h0 + DC_CH, (nch - 1) * DC_CH);
+            wa.issue(g1h, g1l, C, h1, tid);
+            wq.issue(g2h, g2l, C, h1, tid);
+            const size_t to = (size_t)(tid < 200 ? (tid >> 3) : 0) * d.Hd + h1 + 4 * c4;
+            taps = *reinterpret_cast<const floatx4*>(d.wd + to);
+            tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + to);
         }
         // ---- (a) recompute t1c -> P4, silu(t1c) -> P1
         floatx16 t1[TMW];
