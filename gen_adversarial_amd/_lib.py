@@ -60,7 +60,7 @@ class SeExciteDesc(C.Structure):
     _fields_ = [('m', fp), ('w1', fp), ('b1', fp), ('w2', fp), ('b2', fp), ('hid', fp), ('gate', fp),
                 ('dgate', fp), ('pro_scale', fp), ('pro_shift', fp),
                 ('N', i32), ('C', i32), ('Hd', i32), ('P', i32), ('res_scale', f32), ('backward', i32),
-                ('t', fp), ('dout', fp)]
+                ('t', fp), ('dout', fp), ('skip', fp), ('out', fp)]
 
 
 class SeApplyDesc(C.Structure):

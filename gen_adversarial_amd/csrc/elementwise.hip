@@ -76,6 +76,15 @@ __global__ void __launch_bounds__(256) rowchan_reduce_final_kernel(const ga_rowc
 // ---------------------------------------------------------------------------------------------------------------
 // SE excite: relu(linear_1) -> sigmoid(linear_2) (architecture.py:57-58) and its backward.  One block per row.
 // ---------------------------------------------------------------------------------------------------------------
+// out = skip + res_scale * gate * t with the rounding spelled out (one multiply, one fma): ga_se_apply and the merge fused into
+// ga_se_excite must give the same bits wherever the compiler would have contracted differently
+__device__ __forceinline__ floatx4 se_merge_expr(const floatx4 s, const float rs, const floatx4 g, const floatx4 t) {
+    floatx4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(rs * g[e], t[e], s[e]);
+    return o;
+}
+
 __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc d) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* s_in = sm;            // C
@@ -160,7 +169,25 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             } else {
                 for (int j = 0; j < d.Hd; ++j) acc += w[j] * fmaxf(s_hid[j], 0.f);
             }
-            d.gate[(size_t)n * d.C + c] = sigmoidf_(acc);
+            const float gv = sigmoidf_(acc);
+            d.gate[(size_t)n * d.C + c] = gv;
+            if (d.out) s_part[c] = gv;                  // the FC partials are consumed: the gate stays in LDS for the merge below
+        }
+        if (d.out) {
+            // merge of ga_se_apply (skip_mode 0) on this row, t re-read while it is hot in L2 / MALL: one launch less per cell
+            __syncthreads();
+            const int C4m = d.C >> 2;
+            const float* tb = d.t + (size_t)n * d.P * d.C;
+            const float* sb = d.skip ? d.skip + (size_t)n * d.P * d.C : nullptr;
+            float* ob = d.out + (size_t)n * d.P * d.C;
+#pragma unroll 4
+            for (int i = tid; i < d.P * C4m; i += 256) {
+                const int q = i % C4m;
+                const floatx4 t = *reinterpret_cast<const floatx4*>(tb + (size_t)i * 4);
+                const floatx4 g = *reinterpret_cast<const floatx4*>(s_part + 4 * q);
+                const floatx4 s = sb ? *reinterpret_cast<const floatx4*>(sb + (size_t)i * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<floatx4*>(ob + (size_t)i * 4) = se_merge_expr(s, d.res_scale, g, t);
+            }
         }
     } else {
         // ds[c] = dgate * gate * (1 - gate)
@@ -243,7 +270,7 @@ __global__ void __launch_bounds__(256) se_apply_kernel(const ga_se_apply_desc d,
             const float h0l = 1.f - lh, w0l = 1.f - lw;
             s = h0l * (w0l * x00 + lw * x01) + lh * (w0l * x10 + lw * x11);
         }
-        *reinterpret_cast<floatx4*>(d.out + i * 4) = s + d.res_scale * g * t;
+        *reinterpret_cast<floatx4*>(d.out + i * 4) = se_merge_expr(s, d.res_scale, g, t);
     }
 }
 
@@ -1123,6 +1150,7 @@ extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
     if (!d || !d->w1 || !d->b1 || !d->w2 || !d->b2 || !d->hid || !d->gate || d->N <= 0 || d->C <= 0 || d->Hd <= 0) return GA_E_BADARG;
     if (!d->backward && !d->m && !d->t) return GA_E_BADARG;
     if (d->backward && ((!d->dgate && !d->t) || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
+    if (d->out && (d->backward || !d->t || !aligned16(d->out) || (d->skip && !aligned16(d->skip)))) return GA_E_BADARG;
     size_t lds = (size_t)(d->C + d->Hd + 4 + 256) * sizeof(float);     // + [Hd][chunks] partials of the FC phases
     if (d->Hd > 256) return GA_E_UNSUPPORTED;
     if (d->t) {

@@ -236,8 +236,14 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         self.bwd.add(il, name + '.interleave')
         target.g_written = True
 
-    def se_forward(self, name, t: Act, wts, P, res_scale=None):
-        """squeeze + excite; returns (gate, hid) buffers."""
+    # rows up to this many elements get their SE merge (out = skip + res_scale * gate * t) from the squeeze / excite launch itself
+    # (one workgroup per row re-reads its t while it is hot): 4x4x512 29.6 -> 22.5 us, 8x8x256 33.6 -> 26.8 us per cell; at 16x16x128
+    # the two launches are already HBM-bound (50 -> 48 us) and larger images need the wide grid of ga_se_apply
+    SE_FUSED_MERGE_MAX = 16384
+
+    def se_forward(self, name, t: Act, wts, P, res_scale=None, merge=None):
+        """squeeze + excite; returns (gate, hid) buffers.  merge = (skip tensor or None, out tensor): also emit the merge of
+        ga_se_apply (skip_mode 0) from the same launch; the caller checks `se_merges(t, P)` first."""
         n, c = t.n, t.c
         hd = wts['se_w1'].shape[0]
         hid = self.alloc((n, hd))
@@ -250,8 +256,13 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
         e.hid, e.gate, e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = (_ptr(hid), _ptr(gate), n, c, hd, P,
                                                                         RES_SCALE if res_scale is None else res_scale, 0)
-        self.fwd.add(e, f'{name}.se_gate')
+        if merge is not None:
+            e.skip, e.out = _ptr(merge[0]), _ptr(merge[1])
+        self.fwd.add(e, f'{name}.se_gate' + ('+merge' if merge is not None else ''))
         return gate, hid
+
+    def se_merges(self, t: Act, P) -> bool:
+        return P * t.c <= self.SE_FUSED_MERGE_MAX and t.c % 4 == 0
 
     def se_backward(self, name, dout: torch.Tensor, t: Act, wts, gate, hid, P, res_scale=None):
         """emits d(gate) reduction + excite backward; returns the per-row prologue (scale, shift) for the next GEMM."""

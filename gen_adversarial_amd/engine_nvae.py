@@ -27,17 +27,20 @@ class NvaeBuilder:
         self.conv(self.fwd, p + '.conv1', x.t, wts['w1'], t1.t, bias=wts['b1'], K=3, sn=st, pad=1,
                   pro_scale=wts['pro_scale'], pro_shift=wts['pro_shift'], pro_act=L.GA_ACT_SILU)
         self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, pad=1, pro_act=L.GA_ACT_SILU)
-        gate, hid = self.se_forward(p, t2, wts, ho * wo)
         if cell.down:
             sk = Act(self, n, ho, wo, cell.cout, p + '.skip')
             self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sk.t, bias=wts['bs'], K=1, sn=2, pad=0, pro_act=L.GA_ACT_SILU)
             skip_t = sk.t
         else:
             skip_t = x.t
-        a = L.SeApplyDesc()
-        a.skip, a.t, a.gate, a.out = _ptr(skip_t), _ptr(t2.t), _ptr(gate), _ptr(out.t)
-        a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = n, ho, wo, cell.cout, 0, RES_SCALE
-        self.fwd.add(a, p + '.merge')
+        if self.se_merges(t2, ho * wo):
+            gate, hid = self.se_forward(p, t2, wts, ho * wo, merge=(skip_t, out.t))
+        else:
+            gate, hid = self.se_forward(p, t2, wts, ho * wo)
+            a = L.SeApplyDesc()
+            a.skip, a.t, a.gate, a.out = _ptr(skip_t), _ptr(t2.t), _ptr(gate), _ptr(out.t)
+            a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = n, ho, wo, cell.cout, 0, RES_SCALE
+            self.fwd.add(a, p + '.merge')
 
         def backward():
             ps, pb = self.se_backward(p, out.g, t2, wts, gate, hid, ho * wo)
@@ -93,17 +96,20 @@ class NvaeBuilder:
             d.N, d.H, d.W, d.C, d.pro_act, d.up2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
             self.fwd.add(d, p + '.dw5')
             self.conv(self.fwd, p + '.pw2', t2.t, wts['w2'], t3.t, bias=wts['b2'], K=1, pro_act=L.GA_ACT_SILU)
-        gate, hid = self.se_forward(p, t3, wts, H * W)
-        a = L.SeApplyDesc()
-        if up:
-            sl = Act(self, n, h, w, cell.cout, p + '.skip_low')
-            self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sl.t, bias=wts['bs'], K=1)
-            a.skip, a.skip_mode = _ptr(sl.t), 1
+        if not up and self.se_merges(t3, H * W):
+            gate, hid = self.se_forward(p, t3, wts, H * W, merge=(x.t, out.t))
         else:
-            a.skip, a.skip_mode = _ptr(x.t), 0
-        a.t, a.gate, a.out = _ptr(t3.t), _ptr(gate), _ptr(out.t)
-        a.N, a.H, a.W, a.C, a.res_scale = n, H, W, cell.cout, RES_SCALE
-        self.fwd.add(a, p + '.merge')
+            a = L.SeApplyDesc()
+            if up:
+                sl = Act(self, n, h, w, cell.cout, p + '.skip_low')
+                self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sl.t, bias=wts['bs'], K=1)
+                a.skip, a.skip_mode = _ptr(sl.t), 1
+            else:
+                a.skip, a.skip_mode = _ptr(x.t), 0
+            gate, hid = self.se_forward(p, t3, wts, H * W)
+            a.t, a.gate, a.out = _ptr(t3.t), _ptr(gate), _ptr(out.t)
+            a.N, a.H, a.W, a.C, a.res_scale = n, H, W, cell.cout, RES_SCALE
+            self.fwd.add(a, p + '.merge')
 
         def backward():
             ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W)

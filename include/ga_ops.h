@@ -147,6 +147,10 @@ typedef struct ga_se_excite_desc {
      *   forward  m[c]     = (1/P) sum_p t[n,p,c]                       (m input ignored)
      *   backward dgate[c] = res_scale * sum_p dout[n,p,c] * t[n,p,c]   (dgate input ignored)            */
     const float* t; const float* dout;
+    /* forward, fused form only: when out != NULL the same workgroup also writes the merge of ga_se_apply (skip_mode 0),
+     *   out[n,p,c] = skip[n,p,c] + res_scale * gate[n,c] * t[n,p,c]      (skip may be NULL)
+     * — one launch and one pass over t less per cell; same expression, bitwise the result of the separate launch */
+    const float* skip; float* out;
 } ga_se_excite_desc;
 int ga_se_excite(const ga_se_excite_desc* d, void* stream);
 

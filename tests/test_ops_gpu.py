@@ -498,6 +498,23 @@ def test_se_chain(N, H, Cc):
     close(ps2, ps, 1e-6, 'fused ps')
     close(pb2, pb, 1e-6 , 'fused pb')
 
+    # squeeze + excite + merge in one launch: bitwise the gate and the output of the two launches above
+    hid3, g3, out3 = torch.empty_like(hid), torch.empty_like(gd), torch.full_like(out, float('nan'))
+    m = L.SeExciteDesc()
+    m.t, m.w1, m.b1, m.w2, m.b2 = td.data_ptr(), *(v.data_ptr() for v in W)
+    m.hid, m.gate, m.N, m.C, m.Hd, m.P, m.res_scale = hid3.data_ptr(), g3.data_ptr(), N, Cc, Hd, H * H, 0.1
+    m.skip, m.out = sd_.data_ptr(), out3.data_ptr()
+    L.run(m)
+    out2 = torch.empty_like(out)                        # the separate merge on the fused form's gate
+    a.gate, a.out = g2.data_ptr(), out2.data_ptr()
+    L.run(a)
+    torch.cuda.synchronize()
+    assert torch.equal(g3, g2) and torch.equal(out3, out2)
+    m.skip = None
+    L.run(m)
+    torch.cuda.synchronize()
+    close(out3, 0.1 * td * g2.view(N, 1, 1, Cc), 1e-6, 'merge without a skip')
+
 
 @pytest.mark.parametrize('N,h,Cc', [(2, 4, 16), (3, 8, 8), (1, 16, 4), (2, 1, 4)])
 def test_bilinear_skip(N, h, Cc):
