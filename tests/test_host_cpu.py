@@ -380,3 +380,35 @@ def test_trans_defense_plans_build_without_a_gpu():
     assert b.index('latent_mix^T') < b.index(p + 'norm3^T') < b.index('trans.resize_crop^T') < b.index('image_in^T')
     n_of = {n: d.N for d, n in zip(eng.fwd.descs, eng.fwd.names) if hasattr(d, 'N')}
     assert n_of['e4e.input.conv'] == 2 and n_of['conv1.conv'] == 4                             # shared encoder: one pass per image
+
+
+def test_channel_padding_helpers_keep_the_convolution():
+    """folding.pad_conv_out / pad_cols / pad_rows: the engine rounds the 20 latent channels and the 100 mixture logits up to a multiple
+    of 8 (so that the convs around them run on the split-bf16 kernels); padded weights on zero-padded tensors give the same numbers"""
+    from gen_adversarial_amd.folding import conv_bwd_layout, conv_fwd_layout, pad_cols, pad_conv_out, pad_rows
+    g = torch.Generator().manual_seed(3)
+    cin, cout, cp = 6, 5, 8
+    w = torch.randn(cout, cin, 3, 3, generator=g)
+    b = torch.randn(cout, generator=g)
+    f = {'w': conv_fwd_layout(w), 'w_bwd': conv_bwd_layout(w), 'b': b}
+    fp = pad_conv_out(f, cout, cp)
+    assert fp['w'].shape == (cp, 9 * cin) and fp['w_bwd'].shape == (cin, 9 * cp) and fp['b'].shape == (cp,)
+    x = torch.randn(2, cin, 5, 5, generator=g)
+    ref = torch.nn.functional.conv2d(x, w, b, padding=1)
+    wp = fp['w'].view(cp, 3, 3, cin).permute(0, 3, 1, 2)                     # back from [Cout][taps * Cin]
+    got = torch.nn.functional.conv2d(x, wp, fp['b'], padding=1)
+    assert torch.equal(got[:, :cout], ref) and bool((got[:, cout:] == 0).all())
+    # transposed conv of a cotangent whose pad channels are zero: same input gradient
+    cot = torch.randn_like(ref)
+    cotp = torch.zeros(2, cp, 5, 5)
+    cotp[:, :cout] = cot
+    wb = fp['w_bwd'].view(cin, 3, 3, cp).permute(0, 3, 1, 2)
+    wb0 = f['w_bwd'].view(cin, 3, 3, cout).permute(0, 3, 1, 2)
+    assert torch.allclose(torch.nn.functional.conv2d(cotp, wb, padding=1), torch.nn.functional.conv2d(cot, wb0, padding=1), atol=1e-6)
+    # a 1x1 weight whose last n inputs get a padded pitch, and its transpose
+    m = torch.randn(4, 10 + 3, generator=g)
+    mp = pad_cols(m, 10, 3, 8)
+    assert mp.shape == (4, 18) and torch.equal(mp[:, :13], m) and bool((mp[:, 13:] == 0).all())
+    r = pad_rows(m[:, 10:].t().contiguous(), 8)
+    assert r.shape == (8, 4) and torch.equal(r[:3], m[:, 10:].t()) and bool((r[3:] == 0).all())
+    assert pad_cols(m, 10, 3, 3) is m and pad_rows(r, 8) is r
