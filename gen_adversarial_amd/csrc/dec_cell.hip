@@ -13,7 +13,8 @@
 // ahead and registers -> LDS at the top of their chunk: the B-fragments are then 16-B LDS reads (read straight from global
 // memory, one exposed L2 round trip per k step made the kernel 2-3x slower: one wave per SIMD hides nothing).
 // Contractions are the three-MFMA split-bf16 products of conv_bf3 (same operand split, same k order), the depthwise
-// part is the fp32 loop of dwconv5 in the same order: the fused result follows the unfused one to summation order.
+// part is the fp32 loop of dwconv5 in the same order: the fused result is, bit for bit, that of the three launches it replaces
+// (tests/test_dec_cell_gpu.py, tests/test_fullsize_gpu.py).
 //
 // Backward (d loss / d t1 from d loss / d t3; d x is then ONE 1x1 ga_conv2d of it): x AND dt3 = dout * ps[n] + pb[n]
 // resident as A-fragments; per chunk t1c and t2c are recomputed (GEMM1 + dw5), then
