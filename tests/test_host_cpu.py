@@ -412,3 +412,19 @@ def test_channel_padding_helpers_keep_the_convolution():
     r = pad_rows(m[:, 10:].t().contiguous(), 8)
     assert r.shape == (8, 4) and torch.equal(r[:3], m[:, 10:].t()) and bool((r[3:] == 0).all())
     assert pad_cols(m, 10, 3, 3) is m and pad_rows(r, 8) is r
+
+
+def test_fused_decoder_cells_are_chosen_by_launch_size():
+    """Engine plans (dry run): a fused decoder-cell launch walks the hidden width serially, so it pays only when its grid fills
+    the chip — 16 cells at 16 x 16 x 128 (one workgroup per image) from 160 rows, 16 more at 8 x 8 x 256 (two images per workgroup)
+    from 320 rows; the reference protocol of one image x EoT 32 keeps the three unfused launches."""
+    vspec = build_vgg_spec(100, 8)
+    vsd = init_vgg_state_dict(100, 8, 0)
+    sd = init_nvae_state_dict(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, 0)
+    n = len(build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION).groups)
+    store = WeightStore('cpu')
+    for rows, want in ((32, 0), (128, 0), (160, 16), (256, 16), (320, 32)):
+        eng = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=rows, rep=32, alphas=[0.5] * n,
+                     device='meta', dry_run=True, store=store)
+        got = sum(isinstance(d, L.DecCellDesc) for d in eng.fwd.descs)
+        assert got == want and sum(isinstance(d, L.DecCellDesc) for d in eng.bwd.descs) == want, (rows, got)
