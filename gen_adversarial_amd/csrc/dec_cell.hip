@@ -110,6 +110,59 @@ __device__ __forceinline__ void dw_strip(floatx4 (&acc)[SW], const float* base, 
     }
 }
 
+// The SW outputs of a thread as a block of BH rows x BW columns.  At 128 channels (SW = 8) a 2 x 4 block reads a 6 x 8 window
+// (48 16-byte LDS reads) where the 1 x 8 strip read 5 x 12 (60): the depthwise phases are LDS-read bound.  Each output still sums
+// its 25 taps in the order kh, kw: bitwise the strip's result.  Horizontally adjacent blocks (4 pixels = 640 B = 128 B mod 256 B) share
+// a 16-lane LDS phase without bank conflicts; at 256 channels (SW = 4) the 1 x 4 strip of vertically adjacent rows stays.
+template <int BH, int BW>
+__device__ __forceinline__ void dw_tile(floatx4 (&acc)[BH * BW], const float* base, const float* taps, const int PW) {
+    if constexpr (BH == 1) {
+        dw_strip<BW>(acc, base, taps, PW);
+    } else {
+        static_assert(BH == 2, "blocks of one or two rows");
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2 * BW; ++j) acc[j] = zero;
+        floatx4 wprev[5];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {                               // input row r feeds output row 0 (tap row r) and row 1 (tap row r - 1)
+            floatx4 in[BW + 4], wcur[5];
+#pragma unroll
+            for (int j = 0; j < BW + 4; ++j) in[j] = *reinterpret_cast<const floatx4*>(base + (r * PW + j) * DC_PS);
+            if (r < 5) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) wcur[kw] = *reinterpret_cast<const floatx4*>(taps + (r * 5 + kw) * DC_CH);
+#pragma unroll
+                for (int j = 0; j < BW; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw) acc[j] += in[j + kw] * wcur[kw];
+            }
+            if (r > 0) {
+#pragma unroll
+                for (int j = 0; j < BW; ++j)
+#pragma unroll
+                    for (int kw = 0; kw < 5; ++kw) acc[BW + j] += in[j + kw] * wprev[kw];
+            }
+            if (r < 5) {
+#pragma unroll
+                for (int kw = 0; kw < 5; ++kw) wprev[kw] = wcur[kw];
+            }
+        }
+    }
+}
+
+// first pixel of block s (BH x BW outputs); blocks are numbered row-major inside an image
+template <int BH, int BW>
+__device__ __forceinline__ int tile_pixel(const int s, const dc_geom& g) {
+    if constexpr (BH == 1) {
+        return strip_pixel<BW>(s, g);
+    } else {
+        const int H = g.HW >> g.lw, bpr = g.W / BW, nblk = (H / BH) * bpr;
+        const int ni = s / nblk, rem = s - ni * nblk;
+        return ni * g.HW + (rem / bpr) * BH * g.W + (rem % bpr) * BW;
+    }
+}
+
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 
 // One chunk of a [rows][K]-major split-bf16 weight matrix through LDS.  ROWMAJOR_K (the expand conv W1 and, backward, W2^T):
@@ -168,6 +221,7 @@ __device__ __forceinline__ void interleave_mfma_valu() {
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
     constexpr int M = 128 * TMW, KS = C / 16, NT = C / 32, SW = 4 * TMW;
+    constexpr int BH = TMW == 2 ? 2 : 1, BW = SW / BH;      // this thread's SW depthwise outputs: BH rows x BW columns
     using WA = w_chunk<C, true>;
     using WB = w_chunk<C, false>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -220,7 +274,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // this thread's strip of SW pixels (one image row segment) and its window in the framed plane
-    const int p0 = strip_pixel<SW>(strip, gm);
+    const int p0 = tile_pixel<BH, BW>(strip, gm);
     const int win = plane_idx(p0, gm) - 2 * gm.PW - 2;
     int prow[TMW][4];                                   // plane index of accumulator rows 8 q (+ 0..3) of each 32-pixel tile
 #pragma unroll
@@ -267,7 +321,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
         taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o + h1);
         // ---- A: depthwise 5x5 of chunk ch
         floatx4 a[SW];
-        dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
+        dw_tile<BH, BW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
         DC_T(0)
         // ---- B: GEMM1 of chunk ch + 1  ||  SiLU + split of chunk ch -> P2.  One scheduling region per strip pixel: its share of
         // the k steps (6 / 12 MFMAs, the next region's B-fragments already on their way) beside its ~40 VALU instructions.
@@ -306,8 +360,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
                 for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
                 const bf16x4 hi = __builtin_convertvector(v, bf16x4);
                 const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
-                *reinterpret_cast<bf16x4*>(P2h + (p0 + j) * DC_LDB + 4 * c4) = hi;
-                *reinterpret_cast<bf16x4*>(P2l + (p0 + j) * DC_LDB + 4 * c4) = lo;
+                const int pj = p0 + (j / BW) * gm.W + (j % BW);                 // pixel of output j of the block
+                *reinterpret_cast<bf16x4*>(P2h + pj * DC_LDB + 4 * c4) = hi;
+                *reinterpret_cast<bf16x4*>(P2l + pj * DC_LDB + 4 * c4) = lo;
                 interleave_mfma_valu<KPJ * TMW * 3, 42>();
                 __builtin_amdgcn_sched_barrier(0);
                 if (j + 1 < SW) {
@@ -388,6 +443,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
 template <int C, int TMW>
 __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
     constexpr int M = 128 * TMW, KS = C / 16, SW = 4 * TMW;
+    constexpr int BH = TMW == 2 ? 2 : 1, BW = SW / BH;
     using WA = w_chunk<C, true>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wS = smem;                                                   // [25][32] forward taps of the chunk
@@ -439,7 +495,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
             split8(a, b, gh[i][ks], gl[i][ks]);
         }
     }
-    const int p0 = strip_pixel<SW>(strip, gm);
+    const int p0 = tile_pixel<BH, BW>(strip, gm);
     const int ctr = plane_idx(p0, gm);
     const int win = ctr - 2 * gm.PW - 2;
     int prow[TMW][4];
@@ -496,7 +552,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         DC_T(2)
         // ---- (b) t2c = dw5(silu(t1c)) + bd ;  (c) silu'(t2c) -> registers  ||  g = dt3 . W2c^T, one scheduling region per strip pixel
         floatx4 g2[SW];
-        dw_strip<SW>(g2, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
+        dw_tile<BH, BW>(g2, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
         DC_T(3)
         floatx16 g[TMW];
 #pragma unroll
@@ -554,7 +610,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         // ---- (e) ... times silu'(t2c), each thread on its own strip
 #pragma unroll
         for (int j = 0; j < SW; ++j) {
-            floatx4* q = reinterpret_cast<floatx4*>(P1 + (ctr + j) * DC_PS + 4 * c4);
+            floatx4* q = reinterpret_cast<floatx4*>(P1 + (ctr + (j / BW) * gm.PW + (j % BW)) * DC_PS + 4 * c4);
             *q = *q * g2[j];
         }
         __syncthreads();
@@ -562,11 +618,12 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         // ---- (f) dw5^T, times silu'(t1c) -> dt1
         {
             floatx4 a[SW];
-            dw_strip<SW>(a, P1 + win * DC_PS + 4 * c4, wT + 4 * c4, gm.PW);
+            dw_tile<BH, BW>(a, P1 + win * DC_PS + 4 * c4, wT + 4 * c4, gm.PW);
 #pragma unroll
             for (int j = 0; j < SW; ++j) {
-                const floatx4 u = *reinterpret_cast<const floatx4*>(P4 + (p0 + j) * DC_PS + 4 * c4);
-                *reinterpret_cast<floatx4*>(d.y + (pix0 + p0 + j) * d.Hd + h0 + 4 * c4) = a[j] * u;
+                const int pj = p0 + (j / BW) * gm.W + (j % BW);
+                const floatx4 u = *reinterpret_cast<const floatx4*>(P4 + pj * DC_PS + 4 * c4);
+                *reinterpret_cast<floatx4*>(d.y + (pix0 + pj) * d.Hd + h0 + 4 * c4) = a[j] * u;
             }
         }
         DC_T(8)
