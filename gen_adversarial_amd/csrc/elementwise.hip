@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
     if (c < d.C) {
         const float* a = d.a + (size_t)n * d.P * d.C + c;
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
+#pragma unroll 8
         for (int p = pl; p < d.P; p += 16) {
             floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
             if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
@@ -49,6 +50,7 @@ __global__ void __launch_bounds__(256) rowchan_reduce_split_kernel(const ga_rowc
         const float* a = d.a + (size_t)n * d.P * d.C + c;
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
         const int p1 = min(d.P, (seg + 1) * seg_len);
+#pragma unroll 8
         for (int p = seg * seg_len + pl; p < p1; p += PL) {
             floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
             if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
