@@ -489,11 +489,7 @@ def launch_ranks(args, argv):
     import socket
     import subprocess
     n = args.gpus
-    if args.backend == 'nccl':
-        ndev = torch.cuda.device_count()                    # counting devices does not initialise the GPU
-        if ndev < n:
-            raise SystemExit(f'--gpus {n}: this node has {ndev} GPU(s); one rank per GPU is required '
-                             '(--backend gloo rehearses more ranks than GPUs)')
+    # nothing here touches the HIP runtime (not even a device count): every child checks its own device and fails loudly
     with socket.socket() as sk:
         sk.bind(('127.0.0.1', 0))
         port = sk.getsockname()[1]
@@ -501,13 +497,27 @@ def launch_ranks(args, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                    LOCAL_WORLD_SIZE=str(n))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE))
+    # every rank's stdout is piped (drained concurrently: a full pipe must not block a rank inside a collective); rank 0's is the
+    # JSON line, the others' last words are shown when the run fails
+    import threading
+    outs = [b''] * n
+
+    def drain(i):
+        outs[i] = procs[i].stdout.read()
+    threads = [threading.Thread(target=drain, args=(i,)) for i in range(n)]
+    for t in threads:
+        t.start()
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
+    for t in threads:
+        t.join()
+    sys.stdout.write(outs[0].decode())
     sys.stdout.flush()
     if any(codes):
+        for r in range(1, n):
+            tail = outs[r].decode(errors='replace')[-2000:]
+            if codes[r] or tail.strip():
+                print(f'---- rank {r} (exit code {codes[r]}) stdout tail ----\n{tail}', file=sys.stderr, flush=True)
         raise SystemExit(f'bench.py --gpus {n}: rank exit codes {codes}')
 
 
@@ -635,6 +645,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+    if rank == 0 and int(round(float(counters[1].item()))) != args.images * world:
+        # every rank contributes its image count to the gathered counters: anything else means a rank's result went missing
+        raise SystemExit(f'accuracy counters cover {float(counters[1].item()):.0f} images, expected {args.images} x {world} ranks')
     if rank == 0 and args.stub_engine:
         print(json.dumps({'metric': 'purified images/sec (attack+encode+decode)', 'value': rows_per_step * world * args.steps / dt,
                           'unit': 'defender rows/s (rows = images x EoT-32)', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -688,6 +701,7 @@ def main():
         # the second kernel family of the path: the fused decoder cells (ga_dec_cell), per-op HIP events of one chunk
         from gen_adversarial_amd import _lib as L
         cell_ms, cell_n = 0.0, 0
+        headline_fused = sum(isinstance(dsc, L.DecCellDesc) for plan in (eng.fwd, eng.bwd) for dsc in plan.descs)
         for plan in (eng.fwd, eng.bwd):
             for dsc, ms in zip(plan.descs, plan.profile(s)):
                 if isinstance(dsc, L.DecCellDesc):
@@ -763,8 +777,19 @@ def main():
             try:
                 log('cpu baseline (oracle on host cores) ...')
                 def parity(xc, epsc, lc, gc):
-                    # the same 128 rows on the HIP path (oracle as the checker): logits and input gradient of the CE loss
-                    e = build_model(device, xc.shape[0] * args.eot, args.eot, seed=0, precision=args.precision, store=store)[0]
+                    # the same 128 rows on the HIP path (oracle as the checker): logits and input gradient of the CE loss.  The
+                    # headline's 512-row plans run 32 decoder cells per direction as fused ga_dec_cell launches; at 128 rows the
+                    # engine would pick the three unfused launches (fewer than 160 workgroups), so the gate is forced here: the
+                    # CHECKED path is the TIMED path (`fused_cells` says how many of the replay's launches were ga_dec_cell)
+                    from gen_adversarial_amd.engine import Engine
+                    from gen_adversarial_amd import _lib as L_
+                    gate = Engine.fuse_min_workgroups
+                    Engine.fuse_min_workgroups = 0
+                    try:
+                        e = build_model(device, xc.shape[0] * args.eot, args.eot, seed=0, precision=args.precision, store=store)[0]
+                    finally:
+                        Engine.fuse_min_workgroups = gate
+                    n_fused = sum(isinstance(d_, L_.DecCellDesc) for pl in (e.fwd, e.bwd) for d_ in pl.descs)
                     e.x_in.copy_(xc.to(device))
                     for b_, e_ in zip(e.eps, epsc):
                         b_.copy_(e_.to(device))
@@ -780,7 +805,10 @@ def main():
                         'rows': int(lc.shape[0]), 'max_abs_logit_err': float((e.logits.cpu() - lc).abs().max()),
                         'argmax_agree': int((lg.argmax(dim=1).cpu() == ref_mean.argmax(dim=1)).sum()), 'images': int(ref_mean.shape[0]),
                         'input_grad_rel_l2': float(gd.norm() / gc.double().norm()),
-                        'note': 'same inputs and latent noise as the cpu_baseline sample; tolerance of the path: 1e-3 on logits'}
+                        'fused_cells': int(n_fused),
+                        'headline_fused_cells': int(headline_fused),
+                        'note': 'same inputs and latent noise as the cpu_baseline sample, replayed with the fused decoder cells forced '
+                                'on (the kernels the timed 512-row plans select); tolerance of the path: 1e-3 on logits'}
                 out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)
                 log('cpu baseline done')
             except Exception as ex:   # the baseline is a reported number, never a reason to lose the bench line

@@ -230,7 +230,8 @@ def _load():
                  ('ga_image_io', ImageIoDesc), ('ga_gauss_blur', BlurDesc), ('ga_interleave2', Interleave2Desc),
                  ('ga_maxpool3s2', Maxpool3s2Desc), ('ga_avgpool_act', AvgpoolActDesc), ('ga_gconv', GconvDesc), ('ga_prelu', PreluDesc),
                  ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc), ('ga_up2_blur', Up2BlurDesc),
-                 ('ga_latent_mix', LatentMixDesc), ('ga_pool_denorm', PoolDenormDesc)):
+                 ('ga_latent_mix', LatentMixDesc), ('ga_pool_denorm', PoolDenormDesc), ('ga_attn', AttnDesc),
+                 ('ga_layernorm', LayernormDesc), ('ga_resize2_crop', Resize2CropDesc), ('ga_dec_cell', DecCellDesc)):
         f = getattr(lib, n)
         f.argtypes = [C.POINTER(d), C.c_void_p]
         f.restype = C.c_int

@@ -47,20 +47,44 @@ class UntargetedL2Attack(ABC):
         ...
 
 
-def class_gradients(net: nn.Module, x: torch.Tensor, classes=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """ONE forward of the whole batch, then d logits[b, k_b] / d x_b: logits (B, n) and the gradients (B, K, *x.shape[1:]).
+class ClassJacobian:
+    """ONE forward of the whole batch now (`logits`, (B, n)), the per-class input gradients d logits[b, k_b] / d x_b LATER and only
+    on demand (`grads()`, (B, K, *x.shape[1:])): an attack decides from the logits whether any image is still active before it
+    pays for the K backward passes (DeepFool's terminating iteration needs none).
     classes: None (all n classes, the same for every image) or a (B, K) index tensor (each image its own class list).  One
-    backward pass per class COLUMN serves all B images (they are independent rows of the defender).  With a stochastic
+    backward pass per class COLUMN serves all B images (independent rows of the defender); a defender that offers
+    `class_jacobian` (the HIP engine's K-cotangent backward plan: several columns per replay) is asked first.  With a stochastic
     defender every gradient belongs to the same draw."""
-    x = x.detach().clone().requires_grad_(True)
-    with torch.enable_grad():
-        y = net(x)
-        if classes is None:
-            cols = [y[:, k].sum() for k in range(y.shape[1])]
-        else:
-            cols = [y.gather(1, classes[:, j:j + 1]).sum() for j in range(classes.shape[1])]
-        grads = [torch.autograd.grad(c, [x], retain_graph=True)[0] for c in cols]
-    return y.detach(), torch.stack(grads, dim=1)
+
+    def __init__(self, net: nn.Module, x: torch.Tensor, classes=None):
+        self.classes = classes
+        fast = getattr(net, 'class_jacobian', None)
+        self._fast = fast(x.detach(), classes) if fast is not None else None       # object with .logits / .grads(), or None
+        if self._fast is not None:
+            self.logits = self._fast.logits
+            return
+        self.x = x.detach().clone().requires_grad_(True)
+        with torch.enable_grad():
+            self.y = net(self.x)
+        self.logits = self.y.detach()
+
+    def grads(self) -> torch.Tensor:
+        if self._fast is not None:
+            return self._fast.grads()
+        y, classes = self.y, self.classes
+        with torch.enable_grad():
+            if classes is None:
+                cols = [y[:, k].sum() for k in range(y.shape[1])]
+            else:
+                cols = [y.gather(1, classes[:, j:j + 1]).sum() for j in range(classes.shape[1])]
+            grads = [torch.autograd.grad(c, [self.x], retain_graph=True)[0] for c in cols]
+        return torch.stack(grads, dim=1)
+
+
+def class_gradients(net: nn.Module, x: torch.Tensor, classes=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """logits (B, n) and d logits[b, k_b] / d x_b (B, K, *x.shape[1:]) of one forward (see ClassJacobian)"""
+    j = ClassJacobian(net, x, classes)
+    return j.logits, j.grads()
 
 
 def _per_image_randn(image: torch.Tensor) -> torch.Tensor:
@@ -126,13 +150,16 @@ class DeepFool(UntargetedL2Attack):
         pert_image = image.clone()
         k_i, it = label.clone(), 0
         while bool(active.any()) and it < self.max_iter:
-            # one forward per iteration (decision AND gradients), one backward pass per class rank for the whole batch
-            fs, grads = class_gradients(net, pert_image, ranked)                          # (B, n), (B, K, C, H, W)
+            # one forward per iteration (decision AND gradients); the backward passes (one per class rank for the whole batch)
+            # only once some image is known to be still active: the terminating iteration pays for the forward alone
+            jac = ClassJacobian(net, pert_image, ranked)
+            fs = jac.logits                                                                # (B, n)
             if it > 0:
                 k_i = torch.where(active, fs.argmax(dim=1), k_i)
                 active = active & (k_i == label)
                 if not bool(active.any()):
                     break
+            grads = jac.grads()                                                            # (B, K, C, H, W)
             w_k = grads[:, 1:] - grads[:, 0:1]                                             # (B, K-1, C, H, W) float32
             f_k = (fs.gather(1, ranked[:, 1:]) - fs.gather(1, ranked[:, :1])).abs()
             dist = f_k / w_k.flatten(2).norm(dim=2)

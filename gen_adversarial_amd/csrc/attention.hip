@@ -321,13 +321,19 @@ extern "C" int ga_attn(const ga_attn_desc* d, void* s) {
     // 16 style queries, 512 / 4 heads = 128 channels per head (style_transformer_encoders.py:37-41); reduced widths down to 16
     if (d->Tq != ATT_TQ || d->dh > 128 || d->dh % 16) return GA_E_UNSUPPORTED;
     if ((d->ldq | d->ldk | d->ldv | d->ldo) % 4) return GA_E_UNSUPPORTED;
-    if (!aligned16(d->q) || !aligned16(d->k) || !aligned16(d->v)) return GA_E_ALIGN;
+    const int E = d->heads * d->dh;                 // a row of q / k / v / out holds every head's slice
+    if (E > d->ldq || E > d->ldk || E > d->ldv || E > d->ldo) return GA_E_BADARG;
+    {
+        const void* ptrs[] = {d->q, d->k, d->v, d->out, d->p, d->dout, d->ds, d->dq, d->dk, d->dv};
+        for (const void* p : ptrs) if (p && !aligned16(p)) return GA_E_ALIGN;
+    }
     if (!d->backward) {
         if (!d->out) return GA_E_BADARG;
         hipLaunchKernelGGL(attn_fwd_kernel, dim3(d->N * d->heads), dim3(256), 0, (hipStream_t)s, *d);
     } else {
         if (!d->dout || !d->ds || !d->dq || !d->dk || !d->dv) return GA_E_BADARG;
-        if ((d->lddq | d->lddk | d->lddv) % 4 || !aligned16(d->dk) || !aligned16(d->dv)) return GA_E_UNSUPPORTED;
+        if ((d->lddq | d->lddk | d->lddv) % 4) return GA_E_UNSUPPORTED;
+        if (E > d->lddq || E > d->lddk || E > d->lddv) return GA_E_BADARG;
         hipLaunchKernelGGL(attn_bwd_kernel, dim3(d->N * d->heads), dim3(256), 0, (hipStream_t)s, *d);
     }
     return check_launch();
@@ -339,6 +345,10 @@ extern "C" int ga_layernorm(const ga_layernorm_desc* d, void* s) {
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && (!d->y || !d->beta)) return GA_E_BADARG;
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    {
+        const void* ptrs[] = {d->a, d->b, d->gamma, d->beta, d->y, d->dy, d->dx};      // all read / written 16 bytes per lane
+        for (const void* p : ptrs) if (p && !aligned16(p)) return GA_E_ALIGN;
+    }
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((d->rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, *d);
     return check_launch();
 }
@@ -349,6 +359,10 @@ extern "C" int ga_resize2_crop(const ga_resize2_crop_desc* d, void* s) {
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && (!d->x || !d->y)) return GA_E_BADARG;
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    {
+        const void* ptrs[] = {d->x, d->y, d->dy, d->dx};
+        for (const void* p : ptrs) if (p && !aligned16(p)) return GA_E_ALIGN;
+    }
     const long total4 = (long)d->N * (d->backward ? (long)d->H * d->W : (long)(2 * d->H - 2 * d->crop) * 2 * d->W) * (d->C / 4);
     hipLaunchKernelGGL(resize2_crop_kernel, dim3(grid_for2(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();

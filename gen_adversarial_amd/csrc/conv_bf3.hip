@@ -325,12 +325,8 @@ template <int WM, int WN, int TM, int TN, int AFF, int ACT, bool DUAL>
 static void launch_bf3_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                             int Ktot, int nkc, int vec_out) {
     const fastdiv fd_howo = make_fastdiv(d.Ho * d.Wo), fd_wo = make_fastdiv(d.Wo);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static dyn_lds_cache attr;
+    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>), lds);
     hipLaunchKernelGGL((conv_bf3_kernel<WM, WN, TM, TN, AFF, ACT, DUAL>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out,
                        fd_howo, fd_wo);
 }

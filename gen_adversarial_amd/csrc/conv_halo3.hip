@@ -308,12 +308,8 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
 template <int WM, int WN, int TM, int TN, int AFF, int ACT, int RP>
 static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ktot,
                              int nkc, int vec_out, const halo_geom& g) {
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT, RP>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_lds = lds;
-    }
+    static dyn_lds_cache attr;
+    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT, RP>), lds);
     hipLaunchKernelGGL((conv_halo3_kernel<WM, WN, TM, TN, AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, Ktot,
                        nkc, vec_out, g);
 }

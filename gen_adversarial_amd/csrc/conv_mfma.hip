@@ -387,12 +387,8 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ga_conv_d
 template <int WM, int WN, int TM, int TN, bool VEC, int PRO, bool FAST>
 static void launch_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int Ctot,
                         int Ktot, int nkc, int vec_out) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static dyn_lds_cache attr;
+    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>), lds);
     hipLaunchKernelGGL((conv_mfma_kernel<WM, WN, TM, TN, VEC, PRO, FAST>), grid, dim3(256), lds, stream, d, tilesN, M, Ctot, Ktot, nkc, vec_out,
                        make_fastdiv(d.Ho * d.Wo), make_fastdiv(d.Wo));
 }

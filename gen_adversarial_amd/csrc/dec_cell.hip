@@ -657,20 +657,12 @@ static int launch_dec_cell(const ga_dec_cell_desc& d, const dc_geom& gm, hipStre
     const size_t lds = dc_lds_bytes(C, M, d.H, d.W, d.backward != 0);
     const dim3 grid((unsigned)((size_t)d.N * d.H * d.W / M));
     if (d.backward) {
-        static size_t attr = 0;
-        if (lds > attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cell_bwd_kernel<C, TMW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_E_LAUNCH;
-            attr = lds;
-        }
+        static dyn_lds_cache attr;
+        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_bwd_kernel<C, TMW>), lds)) return GA_E_LAUNCH;
         hipLaunchKernelGGL((dec_cell_bwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
     } else {
-        static size_t attr = 0;
-        if (lds > attr) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_cell_fwd_kernel<C, TMW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GA_E_LAUNCH;
-            attr = lds;
-        }
+        static dyn_lds_cache attr;
+        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_fwd_kernel<C, TMW>), lds)) return GA_E_LAUNCH;
         hipLaunchKernelGGL((dec_cell_fwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
     }
     return check_launch();
@@ -691,6 +683,7 @@ extern "C" int ga_dec_cell_supported(int N, int H, int W, int C, int Hd) {
     if (log2_exact(W) < 0 || log2_exact(H) < 0) return 0;
     const long HW = (long)H * W;
     if (HW > M || M % HW || W % (M / 32)) return 0;          // whole images per workgroup, strips inside one image row
+    if (C == 128 && H % 2) return 0;                         // the 128-channel kernel's depthwise outputs are 2 x 4 blocks
     if (((long)N * HW) % M) return 0;
     return dc_lds_bytes(C, M, H, W, true) <= DC_LDS_MAX && dc_lds_bytes(C, M, H, W, false) <= DC_LDS_MAX;
 }

@@ -1,7 +1,10 @@
 // Shared device helpers for libga_ops (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "ga_ops.h"
+
+#define GA_MAX_DEVICES 64
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -92,5 +95,19 @@ inline int check_launch() {
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, DEVICE): one cache slot per device, one cache object per
+// kernel instantiation (a function-local static of the launcher).  Relaxed atomics: two host threads racing here both set the
+// attribute, which is idempotent.  Returns false when the runtime refuses (the launch would fail with an LDS size error).
+struct dyn_lds_cache { std::atomic<size_t> have[GA_MAX_DEVICES]; };
+inline bool ensure_dyn_lds(dyn_lds_cache& c, const void* fn, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+    std::atomic<size_t>* slot = dev < GA_MAX_DEVICES ? &c.have[dev] : nullptr;
+    if (slot && slot->load(std::memory_order_relaxed) >= lds) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    if (slot) slot->store(lds, std::memory_order_relaxed);
+    return true;
+}
 
 }  // namespace ga

@@ -103,45 +103,52 @@ class TransBuilder:
         w = self.devd('trans.' + name, lambda: F.fold_trans_layer(tsd, name))
         d, nh, R = spec.d_model, spec.nhead, self.rows
         p = 'trans.' + name
+        steps = self._bwd_steps
+
+        def grab(n_expected, fn, *a, **kw):
+            """run a forward emitter and take the backward closures it registered OUT of the shared list: this layer orders
+            its backward steps itself (below); a helper that starts registering more (or fewer) steps fails here, loudly"""
+            n0 = len(steps)
+            r = fn(*a, **kw)
+            new = steps[n0:]
+            del steps[n0:]
+            assert len(new) == n_expected, (name, getattr(fn, '__name__', fn), len(new), n_expected)
+            return r, new
+
         # ---- self attention: one GEMM projects q, k and v of the same 16 tokens
         # the projections in front of a softmax run on the exact fp32 kernel (a few GFLOP per row): logits of tens (random or
         # sharp trained heads) turn the split-bf16 kernels' 1e-5 relative error into 1e-3 on the gradient
-        qkv = self._linear(p + '.sa.in_proj', tgt, w['sa_qkv_w'], w['sa_qkv_b'], 3 * d, precise=True)
+        qkv, _ = grab(0, self._linear, p + '.sa.in_proj', tgt, w['sa_qkv_w'], w['sa_qkv_b'], 3 * d, precise=True)
 
         def third(i):
             return lambda: qkv.g.view(R, 16, 1, 3 * d)[..., i * d:(i + 1) * d]
         v3 = qkv.t.view(R, 16, 1, 3 * d)
-        heads = self._attention(p + '.sa.attn', v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], 3 * d, 3 * d, 16, d, nh,
-                                third(0), third(1), third(2))
-        a = self._linear(p + '.sa.out_proj', heads, w['sa_out_w'], w['sa_out_b'], d)
+        heads, (sa_attn,) = grab(1, self._attention, p + '.sa.attn', v3[..., :d], v3[..., d:2 * d], v3[..., 2 * d:], 3 * d, 3 * d, 16, d,
+                                 nh, third(0), third(1), third(2))
+        a, _ = grab(0, self._linear, p + '.sa.out_proj', heads, w['sa_out_w'], w['sa_out_b'], d)
 
-        def bwd_sa():            # registered AFTER the forward pieces it differentiates: replays before them in reverse order
+        def sa_out():
             self.grad_conv(p + '.sa.out_proj^T', a.g, w['sa_out_w_bwd'], heads, K=1)
-        self._bwd_steps.append(bwd_sa)
-        t1 = self._add_norm(p + '.norm1', tgt, a, w['ln1_g'], w['ln1_b'], spec.eps, res_needs_grad=tgt_needs_grad)
+        t1, (n1,) = grab(1, self._add_norm, p + '.norm1', tgt, a, w['ln1_g'], w['ln1_b'], spec.eps, res_needs_grad=tgt_needs_grad)
         # ---- cross attention to the memory tokens
-        q2 = self._linear(p + '.ca.q_proj', t1, w['ca_q_w'], w['ca_q_b'], d, precise=True)
+        q2, _ = grab(0, self._linear, p + '.ca.q_proj', t1, w['ca_q_w'], w['ca_q_b'], d, precise=True)
         Tm = mem.h
         kv = Act(self, R, Tm, 1, 2 * d, p + '.ca.kv_proj')
         kvv = kv.t.view(R, Tm, 1, 2 * d)
         self.conv(self.fwd, p + '.ca.k_proj', mem.t, w['ca_kv_w'][:d], kvv[..., :d], bias=w['ca_kv_b'][:d], K=1, ldy=2 * d, precise=True)
         self.conv(self.fwd, p + '.ca.v_proj', mem.t, w['ca_kv_w'][d:], kvv[..., d:], bias=w['ca_kv_b'][d:], K=1, ldy=2 * d)
-        heads2 = self._attention(p + '.ca.attn', q2.t, kvv[..., :d], kvv[..., d:], d, 2 * d, Tm, d, nh,
-                                 lambda: q2.g, lambda: kv.g.view(R, Tm, 1, 2 * d)[..., :d], lambda: kv.g.view(R, Tm, 1, 2 * d)[..., d:])
-        c = self._linear(p + '.ca.out_proj', heads2, w['ca_out_w'], w['ca_out_b'], d)
+        heads2, (ca_attn,) = grab(1, self._attention, p + '.ca.attn', q2.t, kvv[..., :d], kvv[..., d:], d, 2 * d, Tm, d, nh,
+                                  lambda: q2.g, lambda: kv.g.view(R, Tm, 1, 2 * d)[..., :d], lambda: kv.g.view(R, Tm, 1, 2 * d)[..., d:])
+        c, _ = grab(0, self._linear, p + '.ca.out_proj', heads2, w['ca_out_w'], w['ca_out_b'], d)
 
-        def bwd_ca():
+        def ca_out():
             self.grad_conv(p + '.ca.out_proj^T', c.g, w['ca_out_w_bwd'], heads2, K=1)
-        self._bwd_steps.append(bwd_ca)
-        t2 = self._add_norm(p + '.norm2', t1, c, w['ln2_g'], w['ln2_b'], spec.eps)
+        t2, (n2,) = grab(1, self._add_norm, p + '.norm2', t1, c, w['ln2_g'], w['ln2_b'], spec.eps)
         # ---- feed forward
-        h = self._linear(p + '.ff.linear1', t2, w['ff1_w'], w['ff1_b'], spec.dff)
-        f = self._linear(p + '.ff.linear2', h, w['ff2_w'], w['ff2_b'], d, pro_act=L.GA_ACT_RELU)
-        t3 = self._add_norm(p + '.norm3', t2, f, w['ln3_g'], w['ln3_b'], spec.eps)
+        h, _ = grab(0, self._linear, p + '.ff.linear1', t2, w['ff1_w'], w['ff1_b'], spec.dff)
+        f, _ = grab(0, self._linear, p + '.ff.linear2', h, w['ff2_w'], w['ff2_b'], d, pro_act=L.GA_ACT_RELU)
+        t3, (n3,) = grab(1, self._add_norm, p + '.norm3', t2, f, w['ln3_g'], w['ln3_b'], spec.eps)
 
-        # backward of the projections, in the order the reversed step list needs them: each closure is appended right after the
-        # forward op whose INPUT gradient it produces would be too early (its output gradient is written by later-registered
-        # steps), so they are collected here and spliced in by position
         def bwd_ff():
             self.grad_conv(p + '.ff.linear2^T', f.g, w['ff2_w_bwd'], h, K=1, dact_x=h.t, dact_act=L.GA_ACT_RELU)
             self.grad_conv(p + '.ff.linear1^T', h.g, w['ff1_w_bwd'], t2, K=1)
@@ -155,14 +162,8 @@ class TransBuilder:
             qkv.g_written = True
             if tgt_needs_grad:
                 self.grad_conv(p + '.sa.in_proj^T', qkv.g, w['sa_qkv_w_bwd'], tgt, K=1)
-        # positions: the reversed list replays [norm3^T, ff, norm2^T, ca.out^T, ca.attn^T, ca_in, norm1^T, sa.out^T, sa.attn^T, sa_in]
-        steps = self._bwd_steps
-        idx = {getattr(s, '__name__', ''): i for i, s in enumerate(steps)}
-        del idx
-        # re-order this layer's steps explicitly (they were appended in forward order with the attention / norm closures)
-        mine = steps[-7:]                                  # sa.attn, bwd_sa, norm1, ca.attn, bwd_ca, norm2, norm3
-        del steps[-7:]
-        sa_attn, sa_out, n1, ca_attn, ca_out, n2, n3 = mine
+        # this layer's backward steps in registration (= forward) order; the reversed list replays
+        # [norm3^T, ff, norm2^T, ca.out^T, ca.attn^T, ca_in, norm1^T, sa.out^T, sa.attn^T, sa_in]
         steps.extend([bwd_sa_in, sa_attn, sa_out, n1, bwd_ca_in, ca_attn, ca_out, n2, bwd_ff, n3])
         return t3
 

@@ -29,31 +29,46 @@ def assert_grad_close(got, g, gf, tol, what='input gradient', max_masked=0.2):
     return K.assert_grad_close(got.detach().cpu().float(), g, gf, tol, what, max_masked)
 
 
-def engine_candidates(eng):
-    """every stored activation of the engine ([N,H,W,C] device tensors) as NCHW CPU tensors"""
-    return [a.t.detach().permute(0, 3, 1, 2).float().cpu() for a in eng.acts.values() if a.t.dim() == 4]
+def engine_candidates(eng, rows=None):
+    """every stored activation of the engine ([N,H,W,C] device tensors) as NCHW CPU tensors; rows: a slice of the engine's rows
+    (an oracle run on a few rows of a large plan: rows are independent)"""
+    out = []
+    for a in eng.acts.values():
+        if a.t.dim() != 4:
+            continue
+        t = a.t.detach()
+        if rows is not None and t.shape[0] == eng.rows:
+            t = t[rows]
+        out.append(t.permute(0, 3, 1, 2).float().cpu())
+    return out
 
 
-def assert_grad_given_engine_decisions(eng, loss_fn, x, got, tol=1e-3, what='input gradient', max_margin=1e-3,
-                                       min_matched=1, golden=None):
+def assert_grad_given_engine_decisions(eng, loss_fn, x, got, tol=1e-3, what='input gradient', max_margin=1e-4,
+                                       min_matched=1, golden=None, rows=None, allow_unmatched=0):
     """(a) + (b) above.  loss_fn(x) -> scalar evaluates the ORACLE; eng is the engine whose last forward produced `got`.
     golden: optional (reference gradient from a golden file, the oracle's own gradient computed HERE).  The two agree at 1e-5
     where the golden was made (tests/test_oracle_golden.py); on another CPU the oracle can decide a near-tie the other way
     (different summation order), which moves that SAMPLE's gradient.  Samples (rows) on which this machine's oracle still
     reproduces the golden are compared against the reference's numbers; the others are reported and covered by the
     oracle-replay comparison alone."""
-    small = [t.detach().float().cpu() for t in getattr(eng, 'small_kinks', [])]      # SE hidden pre-activations, in call order
-    with K.replaying(engine_candidates(eng), small=small) as rp:
+    small = [t.detach() for t in getattr(eng, 'small_kinks', [])]                    # SE hidden pre-activations, in call order
+    small = [(t[rows] if rows is not None and t.shape[0] == eng.rows else t).float().cpu() for t in small]
+    with K.replaying(engine_candidates(eng, rows), small=small) as rp:
         xr = x.detach().clone().requires_grad_(True)
         (g,) = torch.autograd.grad(loss_fn(xr), [xr])
     got = got.detach().cpu().float()
     scale = max(g.abs().max().item(), 1e-30)
     err = (got - g).abs().max().item() / scale
     print(f'   {what}: max err {err:.2e} of max |g| {scale:.2e} given the engine\'s decisions; {rp.summary()}')
+    # A site of >= 48 decisions that found no engine tensor keeps the ORACLE's decisions: the comparison below would then no longer be
+    # "given the engine's decisions" there.  That is a failure (VERDICT r02 weak #9), not a remark: `allow_unmatched` is the
+    # number of such sites a caller can justify (tensors the engine provably does not keep), 0 by default.  Sites with fewer
+    # decisions (SE hidden units) are handed over in call order (`small`) and only listed when they miss.
+    big = [u for u in rp.unmatched if torch.Size(u[1]).numel() >= 48]
     if rp.unmatched:
-        big = [u for u in rp.unmatched if len(u) > 2 and u[2] > 0.9 and torch.Size(u[1]).numel() >= 48]
-        print(f'      {len(rp.unmatched)} unmatched sites keep the oracle\'s decisions (SE hidden units and other tensors the engine does '
-              f'not store); closest misses: {big[:6]}')
+        print(f'      {len(rp.unmatched)} unmatched sites keep the oracle\'s decisions; of >= 48 decisions: {big[:8]}')
+    assert len(big) <= allow_unmatched, (f'{what}: {len(big)} kink sites of >= 48 decisions matched no engine activation '
+                                         f'(allowed {allow_unmatched}): {big[:8]}')
     assert rp.matched >= min_matched, f'{what}: only {rp.matched} kink sites matched to engine activations'
     assert rp.worst_margin <= max_margin, f'{what}: a decision flipped {rp.worst_margin:.2e} (relative) away from its tie'
     assert err <= tol, f'{what}: {err:.2e} (relative to max |g|) with the engine\'s own decisions replayed'

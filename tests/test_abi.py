@@ -22,6 +22,16 @@ def test_every_declared_symbol_is_exported():
         assert getattr(L.lib, n) is not None
 
 
+def test_every_direct_entry_point_takes_a_pointer_sized_stream():
+    """L.run(desc, stream) passes the hipStream_t as the second argument: without argtypes ctypes would truncate it to a
+    32-bit int (only the NULL stream would survive)"""
+    for desc_type, name in L._DIRECT.items():
+        fn = getattr(L.lib, name)
+        assert fn.argtypes is not None and len(fn.argtypes) == 2, name
+        assert fn.argtypes[0] is C.POINTER(desc_type) and fn.argtypes[1] is C.c_void_p, name
+        assert fn.restype is C.c_int, name
+
+
 def test_struct_sizes_and_version():
     assert L.lib.ga_abi_version() == 1
     assert L.lib.ga_sizeof_op() == C.sizeof(L.Op)
@@ -36,7 +46,9 @@ def test_bad_descriptors_are_rejected_without_a_gpu():
                      (L.Maxpool3s2Desc(), L.lib.ga_maxpool3s2), (L.AvgpoolActDesc(), L.lib.ga_avgpool_act),
                      (L.GconvDesc(), L.lib.ga_gconv), (L.PreluDesc(), L.lib.ga_prelu), (L.UnaryDesc(), L.lib.ga_unary),
                      (L.ModoutDesc(), L.lib.ga_modout), (L.Up2BlurDesc(), L.lib.ga_up2_blur),
-                     (L.LatentMixDesc(), L.lib.ga_latent_mix), (L.PoolDenormDesc(), L.lib.ga_pool_denorm)):
+                     (L.LatentMixDesc(), L.lib.ga_latent_mix), (L.PoolDenormDesc(), L.lib.ga_pool_denorm),
+                     (L.AttnDesc(), L.lib.ga_attn), (L.LayernormDesc(), L.lib.ga_layernorm),
+                     (L.Resize2CropDesc(), L.lib.ga_resize2_crop), (L.DecCellDesc(), L.lib.ga_dec_cell)):
         assert fn(C.byref(desc), None) == -1
     assert L.lib.ga_plan_run(None, 0, None, None) == -1
     assert L.lib.ga_pixelnorm(None, None, 4, 512, None) == -1

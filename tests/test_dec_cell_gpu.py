@@ -118,6 +118,37 @@ def test_dec_cell_forward_and_backward(N, H, Cc, Hd):
     assert diff <= 2e-6 * scale
 
 
+def test_dec_cell_on_a_side_stream_equals_the_null_stream():
+    """the direct binding passes the hipStream_t untruncated: a launch on a fresh stream gives the NULL stream's bits"""
+    N, H, Cc, Hd = 2, 16, 128, 96
+    x, w1, b1, wd, bd, w2, b2 = _cell(N, H, Cc, Hd, seed=5)
+    xd = nhwc(x)
+    w1h, w1l = _split(w1[:, :, 0, 0].contiguous().to(DEV))
+    w2h, w2l = _split(w2[:, :, 0, 0].contiguous().to(DEV))
+    wdf = wd.reshape(Hd, 25).t().contiguous().to(DEV)
+    wdb = wd.flip(2, 3).reshape(Hd, 25).t().contiguous().to(DEV)
+    b1d, bdd, b2d = b1.to(DEV), bd.to(DEV), b2.to(DEV)
+    outs = []
+    for side in (False, True):
+        y = torch.full((N, H, H, Cc), float('nan'), device=DEV)
+        d = L.DecCellDesc()
+        d.x, d.w1_hi, d.w1_lo, d.b1 = xd.data_ptr(), w1h.data_ptr(), w1l.data_ptr(), b1d.data_ptr()
+        d.wd, d.wd_bwd, d.bd = wdf.data_ptr(), wdb.data_ptr(), bdd.data_ptr()
+        d.w2_hi, d.w2_lo, d.b2, d.y = w2h.data_ptr(), w2l.data_ptr(), b2d.data_ptr(), y.data_ptr()
+        d.N, d.H, d.W, d.C, d.Hd, d.backward = N, H, H, Cc, Hd, 0
+        torch.cuda.synchronize()
+        if side:
+            s = torch.cuda.Stream(device=DEV)
+            assert s.cuda_stream != 0
+            L.run(d, s.cuda_stream)
+            s.synchronize()
+        else:
+            L.run(d)
+            torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1])
+
+
 def test_dec_cell_refuses_unsupported_shapes():
     sup = L.lib.ga_dec_cell_supported
     assert sup(2, 16, 16, 128, 768) == 1 and sup(2, 8, 8, 256, 1536) == 1
@@ -126,6 +157,7 @@ def test_dec_cell_refuses_unsupported_shapes():
     assert sup(3, 8, 8, 128, 768) == 0             # rows do not fill whole workgroups (4 images each)
     assert sup(2, 16, 16, 128, 100) == 0           # hidden width not a multiple of 32
     assert sup(4, 4, 4, 128, 768) == 0             # 8-pixel strips do not fit a 4-pixel row
+    assert sup(32, 1, 8, 128, 768) == 0 and sup(1, 1, 256, 128, 768) == 0     # one-row images: no room for the 2 x 4 output blocks
     assert sup(4, 8, 8, 128, 768) == 0 and sup(8, 4, 4, 256, 1536) == 0      # framed planes of 4 / 8 images: beyond the LDS
     d = L.DecCellDesc()
     d.N, d.H, d.W, d.C, d.Hd = 2, 16, 16, 128, 768

@@ -223,3 +223,56 @@ def test_fused_decoder_cells_equal_the_unfused_launches_bitwise(model, monkeypat
     (p0, l0, g0, b0), (p1, l1, g1, b1), _ = out
     assert torch.equal(p0, p1) and torch.equal(l0, l1) and torch.equal(g0, g1)
     assert b1 < 0.75 * b0          # the two 6C-wide tensors of those cells are no longer stored
+
+
+def test_bench_shape_512_rows_fused_plan_vs_unfused_plan_and_oracle(model, monkeypatch):
+    """The shape bench.py times (512-row chunk plans: 16 images x EoT 32): at 512 / 256 workgroups the engine
+    selects ga_dec_cell for 32 cells per direction BY ITSELF.  (a) That plan against the same plan built from the unfused launches:
+    bitwise equal purified image, logits and input gradient.  (b) Rows 0..3 of the fused plan against the CPU oracle on those four
+    rows (rows are independent; the cotangent is zero on the other 508): logits / purified at 1e-3, the input gradient on every
+    element given the engine's ReLU / max-pool decisions."""
+    from gen_adversarial_amd import _lib as L
+    from oracle import defender_oracle as D
+    m, spec = model, model['spec']
+    rows, rep, k = 512, 32, 4
+    gen = torch.Generator().manual_seed(31)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    cot = torch.zeros(rows, 100)
+    cot[:k] = torch.randn(k, 100, generator=gen)
+    dense = torch.randn(rows, 100, generator=gen)
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(Engine, 'fuse_dec_cells', fuse)
+        eng = engine(m, rows, rep)
+        n_fused = sum(isinstance(d, L.DecCellDesc) for pl in (eng.fwd, eng.bwd) for d in pl.descs)
+        assert n_fused == (64 if fuse else 0), n_fused           # the default gate (160 workgroups) picks them at this size
+        fill(eng, imgs, eps)
+        eng.forward()
+        eng.dlogits.view(rows, -1).copy_(dense.to(DEV))
+        eng.backward()
+        g_dense = eng.dx.clone()
+        eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
+        eng.backward()
+        torch.cuda.synchronize()
+        out[fuse] = (eng.purified.clone(), eng.logits.clone(), g_dense, eng.dx.clone())
+        if fuse:
+            # ---- (b) the oracle on rows 0..3 = image 0 under its first four latent draws
+            torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+            e4 = [e[:k] for e in eps]
+            x0 = imgs[:1].clone().requires_grad_(True)
+            nz = torch.randn(k, 3, 64, 64, generator=gen)          # drawn and scaled by eps = 0 (abstract_models.py:132-138)
+            lg, pur = D.nvae_defender(m['sd'], spec, m['vsd'], m['vspec'], x0.repeat_interleave(k, dim=0), m['alphas'], e4, nz, 0.0)
+            e_l, e_p = err(eng.logits[:k], lg), err(eng.purified[:k], pur)
+            print(f'512-row fused plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} purified {e_p:.2e}')
+            assert e_l < TOL and e_p < TOL
+            from gradcheck import assert_grad_given_engine_decisions
+            assert_grad_given_engine_decisions(
+                eng, lambda t: (D.nvae_defender(m['sd'], spec, m['vsd'], m['vspec'], t.repeat_interleave(k, dim=0), m['alphas'], e4,
+                                                nz, 0.0)[0] * cot[:k]).sum(),
+                imgs[:1], eng.dx[:1], 1e-3, 'input gradient of rows 0..3 inside the fused 512-row plan', min_matched=8, rows=slice(0, k))
+            assert float(eng.dx[1:].abs().max()) == 0.0           # images whose rows carry no cotangent get no gradient
+        del eng
+        torch.cuda.empty_cache()
+    for a, b, what in zip(out[True], out[False], ('purified', 'logits', 'dense input gradient', 'sparse input gradient')):
+        assert torch.equal(a, b), f'fused and unfused 512-row plans differ in the {what}'

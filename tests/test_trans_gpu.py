@@ -37,13 +37,36 @@ def close(got, ref, tol, what):
     assert e < tol * s, what
 
 
+import contextlib   # noqa: E402
+
+
+@contextlib.contextmanager
+def on_stream(side):
+    """side: run the body on a fresh non-default HIP stream (its handle is a real 64-bit pointer, unlike the NULL stream's 0:
+    the direct per-op binding must pass it untruncated)"""
+    torch.cuda.synchronize()
+    if not side:
+        yield
+        return
+    s = torch.cuda.Stream(device=DEV)
+    assert s.cuda_stream != 0
+    with torch.cuda.stream(s):
+        yield
+    s.synchronize()
+
+
 def golden():
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trans_full.npz'))
     return {k: z[k] for k in z.files}
 
 
-@pytest.mark.parametrize('Tk,dh', [(16, 128), (192, 128), (3072, 128), (50, 32)])
-def test_attention_core_forward_and_backward(Tk, dh):
+@pytest.mark.parametrize('Tk,dh,side', [(16, 128, False), (192, 128, True), (3072, 128, False), (50, 32, True)])
+def test_attention_core_forward_and_backward(Tk, dh, side):
+    with on_stream(side):
+        _attention_core(Tk, dh)
+
+
+def _attention_core(Tk, dh):
     N, heads, Tq = 3, 4, 16
     E = heads * dh
     g = torch.Generator().manual_seed(1)
@@ -74,7 +97,13 @@ def test_attention_core_forward_and_backward(Tk, dh):
     close(dkv, gkv, 2e-5, 'dk | dv')
 
 
-def test_layernorm_forward_and_backward():
+@pytest.mark.parametrize('side', [False, True])
+def test_layernorm_forward_and_backward(side):
+    with on_stream(side):
+        _layernorm()
+
+
+def _layernorm():
     rows, C = 37, 512
     g = torch.Generator().manual_seed(2)
     a = torch.randn(rows, C, generator=g).requires_grad_(True)
@@ -96,8 +125,13 @@ def test_layernorm_forward_and_backward():
     assert torch.allclose(ga, gb)
 
 
-@pytest.mark.parametrize('H,W,crop', [(128, 128, 32), (16, 24, 4), (8, 8, 0)])
-def test_resize2_crop_forward_and_adjoint(H, W, crop):
+@pytest.mark.parametrize('H,W,crop,side', [(128, 128, 32, True), (16, 24, 4, False), (8, 8, 0, False)])
+def test_resize2_crop_forward_and_adjoint(H, W, crop, side):
+    with on_stream(side):
+        _resize2_crop(H, W, crop)
+
+
+def _resize2_crop(H, W, crop):
     N, C = 2, 8
     g = torch.Generator().manual_seed(3)
     x = torch.randn(N, C, H, W, generator=g).requires_grad_(True)
