@@ -317,6 +317,14 @@ def secondary_measurements(out, args, device, model, store, x, labels):
         free_gpu_memory()
     except Exception as ex:
         sec['reference_protocol_1_image'] = {'rows_per_s_eager': None, 'what': f'failed: {ex}'}
+    # ---- per-class input gradients (DeepFool: 10 classes; FAB on the ids experiment: 100) — one forward + one backward per class
+    #      (the reference: src/attacks/untargeted.py:526-560, :605-635) against the K-cotangent backward plan
+    try:
+        log('secondary: per-class gradients, K-cotangent plan ...')
+        sec['class_jacobian'] = class_jacobian_measurement(args, device, store)
+    except Exception as ex:
+        sec['class_jacobian'] = {'what': f'failed: {type(ex).__name__}: {ex}'}
+    free_gpu_memory()
     # ---- configs[2]: e4e + StyleGAN2-1024 defender, ResNet-50, 256 px, 64 rows per step, input noise eps 4.0
     try:
         log('secondary: configs[2] e4e + StyleGAN2 defender ...')
@@ -331,6 +339,44 @@ def secondary_measurements(out, args, device, model, store, x, labels):
     except Exception as ex:
         sec['configs4_trans_defender'] = {'rows_per_s': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
     free_gpu_memory()
+
+
+def class_jacobian_measurement(args, device, store):
+    """What one DeepFool iteration (10 class gradients) and one FAB gradient evaluation on the ids defender (100 classes) cost:
+    ONE forward + C backward replays of the plain plan (the reference's per-class `.backward(retain_graph=True)` loop) against ONE
+    forward + ceil(C / K) replays of the K-cotangent plan, for the reference's protocol (1 image x EoT 32,
+    K = 16) and a 16-image batch (512 rows, K = 4).  API default: encoder shared by the EoT replicas (no input noise)."""
+    import math
+    from gen_adversarial_amd.engine import Engine
+    from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION
+    res = {}
+    for images, K in ((1, 16), (16, 4)):
+        rows = images * args.eot
+        e1, model = build_model(device, rows, args.eot, seed=0, precision=args.precision, share_encoder=True, store=store)
+        sd, vsd, vspec, alphas = model
+        eK = Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=rows, rep=args.eot, alphas=alphas, temperature=0.6,
+                    noise_eps=0.0, device=device, precision=args.precision, share_encoder=True, store=store, cot_rep=K)
+        for e in (e1, eK):
+            e.x_in.uniform_()
+            for b in e.eps:
+                b.normal_()
+            e.dlogits.normal_()
+
+        def iteration(e, C):
+            e.forward()
+            for _ in range(math.ceil(C / e.cot_rep)):
+                e.backward()
+        entry = {'rows': rows, 'K': K, 'what': f'{images} image(s) x EoT {args.eot}: one forward + the input gradients of C class logits'}
+        for C, name in ((10, 'deepfool_10_classes'), (100, 'fab_100_classes')):
+            n = 3 if C * rows > 2000 else 10
+            t1 = _time_steps(lambda: iteration(e1, C), n, warm=1)
+            tK = _time_steps(lambda: iteration(eK, C), n, warm=1)
+            entry[name] = {'ms_per_class_loop': t1 * 1e3, 'backward_replays_per_class_loop': C,
+                           'ms_k_cotangent': tK * 1e3, 'backward_replays_k_cotangent': math.ceil(C / K), 'speedup': t1 / tK}
+        res[f'{images}_images'] = entry
+        del e1, eK
+        free_gpu_memory()
+    return res
 
 
 def build_trans_defender(device, rows, eot, precision):

@@ -41,14 +41,14 @@ class ConvDesc(C.Structure):
                 ('KH', i32), ('KW', i32), ('sn', i32), ('sd', i32), ('pad', i32),
                 ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
                 ('splits', i32), ('ws', fp), ('ws_floats', C.c_long),
-                ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('_reserved', C.c_uint),
+                ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('dact_rep', i32),
                 ('w_hi', fp), ('w_lo', fp), ('addend_rep', i32), ('flags', i32)]
 
 
 class DwDesc(C.Structure):
     _fields_ = [('x', fp), ('w', fp), ('bias', fp), ('dact_x', fp), ('y', fp),
                 ('N', i32), ('H', i32), ('W', i32), ('C', i32),
-                ('pro_act', i32), ('dact_act', i32), ('up2', i32), ('pool2', i32)]
+                ('pro_act', i32), ('dact_act', i32), ('up2', i32), ('pool2', i32), ('act_rep', i32), ('_reserved', i32)]
 
 
 class ReduceDesc(C.Structure):
@@ -60,7 +60,7 @@ class SeExciteDesc(C.Structure):
     _fields_ = [('m', fp), ('w1', fp), ('b1', fp), ('w2', fp), ('b2', fp), ('hid', fp), ('gate', fp),
                 ('dgate', fp), ('pro_scale', fp), ('pro_shift', fp),
                 ('N', i32), ('C', i32), ('Hd', i32), ('P', i32), ('res_scale', f32), ('backward', i32),
-                ('t', fp), ('dout', fp), ('skip', fp), ('out', fp)]
+                ('t', fp), ('dout', fp), ('skip', fp), ('out', fp), ('act_rep', i32), ('_reserved', i32)]
 
 
 class SeApplyDesc(C.Structure):
@@ -77,24 +77,24 @@ class SamplerDesc(C.Structure):
                 ('z', fp), ('dz', fp), ('dmu_q', fp), ('dp', fp),
                 ('N', i32), ('h', i32), ('w', i32), ('NL', i32),
                 ('alpha', f32), ('one_minus_alpha', f32), ('temp', f32), ('backward', i32),
-                ('q_rep', i32), ('dmu_q_rows', fp), ('ldz', i32), ('_reserved', i32)]
+                ('q_rep', i32), ('dmu_q_rows', fp), ('ldz', i32), ('act_rep', i32)]
 
 
 class DmlDesc(C.Structure):
     _fields_ = [('logits', fp), ('ld', i32), ('nmix', i32), ('img_nchw', fp), ('img_nhwc', fp),
                 ('dimg_nhwc', fp), ('dimg_nchw', fp), ('dlogits', fp),
-                ('N', i32), ('H', i32), ('W', i32), ('backward', i32), ('ld_img', i32), ('_reserved', i32)]
+                ('N', i32), ('H', i32), ('W', i32), ('backward', i32), ('ld_img', i32), ('act_rep', i32)]
 
 
 class MaxpoolDesc(C.Structure):
     _fields_ = [('x', fp), ('y', fp), ('dy', fp), ('dx', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32),
-                ('backward', i32)]
+                ('backward', i32), ('act_rep', i32)]
 
 
 class ImageIoDesc(C.Structure):
     _fields_ = [('x_nchw', fp), ('noise_nchw', fp), ('noise_coef', fp), ('y_nhwc', fp), ('dy_nhwc', fp),
                 ('dx_nchw', fp), ('N', i32), ('C', i32), ('H', i32), ('W', i32), ('rep', i32), ('backward', i32),
-                ('ld', i32), ('s2d', i32)]
+                ('ld', i32), ('s2d', i32), ('cot_rep', i32), ('_reserved', i32)]
 
 
 class AxpbyDesc(C.Structure):
@@ -113,7 +113,7 @@ class RepSumDesc(C.Structure):
 class Interleave2Desc(C.Structure):
     _fields_ = [('s', fp * 4), ('y', fp), ('dact_x', fp), ('dact_scale', fp), ('dact_shift', fp), ('addend', fp),
                 ('addend2', fp), ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('dact_act', i32), ('dact_prelu', i32),
-                ('lds', i32), ('_reserved', i32)]
+                ('lds', i32), ('dact_rep', i32)]
 
 
 class Maxpool3s2Desc(C.Structure):
@@ -184,7 +184,7 @@ class Resize2CropDesc(C.Structure):
 class DecCellDesc(C.Structure):
     _fields_ = [('x', fp), ('w1_hi', fp), ('w1_lo', fp), ('b1', fp), ('wd', fp), ('wd_bwd', fp), ('bd', fp),
                 ('w2_hi', fp), ('w2_lo', fp), ('b2', fp), ('dout', fp), ('pro_scale', fp), ('pro_shift', fp), ('y', fp),
-                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Hd', i32), ('backward', i32)]
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Hd', i32), ('backward', i32), ('act_rep', i32), ('_reserved', i32)]
 
 
 class _OpUnion(C.Union):
@@ -215,7 +215,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op', 'ga_debug_set_conv_row_limit']
 
 
@@ -263,6 +263,10 @@ def _load():
     lib.ga_dec_cell_supported.argtypes = [C.c_int] * 5
     lib.ga_dec_cell_supported.restype = C.c_int
     lib.ga_debug_set_conv_row_limit.argtypes = [C.c_long]
+    lib.ga_microbench_hbm_copy.argtypes = [fp, fp, C.c_long, C.c_void_p]
+    lib.ga_microbench_hbm_copy.restype = C.c_int
+    lib.ga_microbench_mfma_bf16.argtypes = [fp, C.c_int, C.c_int, C.c_void_p]
+    lib.ga_microbench_mfma_bf16.restype = C.c_int
     if lib.ga_sizeof_op() != C.sizeof(Op):
         raise ImportError(f'ABI mismatch: library ga_op is {lib.ga_sizeof_op()} bytes, binding is {C.sizeof(Op)}')
     return lib

@@ -6,12 +6,19 @@
 
 namespace ga {
 
+// row of dact_x for output pixel m: with K cotangents per saved activation (dact_rep = K > 1) output row n reads row n / K
+__device__ __forceinline__ size_t dact_row(const ga_conv_desc& d, const size_t m, const int HoWo) {
+    if (d.dact_rep <= 1) return m;
+    const size_t n = m / (size_t)HoWo;
+    return (n / (size_t)d.dact_rep) * (size_t)HoWo + (m - n * (size_t)HoWo);
+}
+
 // epilogue on 4 consecutive channels of one output pixel (vector form)
 __device__ __forceinline__ void epilogue4(const ga_conv_desc& d, const int m, const int co, floatx4 v, const int HoWo) {
     if (d.bias) v += *reinterpret_cast<const floatx4*>(d.bias + co);
     if ((d.flags & GA_CONV_ADDEND_PRE_DACT) && d.addend) v += *reinterpret_cast<const floatx4*>(d.addend + (size_t)m * d.ldadd + co);
     if (d.dact_x) {
-        floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)m * d.lddact + co);
+        floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + dact_row(d, (size_t)m, HoWo) * d.lddact + co);
         floatx4 ds = {1.f, 1.f, 1.f, 1.f};
         if (d.flags & GA_CONV_DACT_PRELU) {
             ds = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
@@ -44,9 +51,9 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
         float ds = 1.f, db = 0.f;
         if (d.dact_scale) { ds = d.dact_scale[co]; db = d.dact_shift[co]; }
         if (d.flags & GA_CONV_DACT_PRELU) {
-            v *= d.dact_x[(size_t)m * d.lddact + co] > 0.f ? 1.f : ds;
+            v *= d.dact_x[dact_row(d, (size_t)m, HoWo) * d.lddact + co] > 0.f ? 1.f : ds;
         } else {
-            const float u = d.dact_x[(size_t)m * d.lddact + co] * ds + db;
+            const float u = d.dact_x[dact_row(d, (size_t)m, HoWo) * d.lddact + co] * ds + db;
             v *= act_bwd_fast(u, d.dact_act) * ds;
         }
     }
@@ -114,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                 if (d.dact_x) {
 #pragma unroll
                     for (int k = 0; k < NB; ++k) {
-                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
+                        const size_t m = ok[k] ? dact_row(d, (size_t)(m0 + rb0 + k * ROWS), HoWo) : 0;
                         u[k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
                     }
                 }

@@ -456,6 +456,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
     if (d.addend && d.ldadd < d.Cout) return GA_E_BADARG;
     if (d.addend2 && d.ldadd2 < d.Cout) return GA_E_BADARG;
     if (d.dact_x && d.lddact < d.Cout) return GA_E_BADARG;
+    if (d.dact_x && d.dact_rep > 1 && d.N % d.dact_rep) return GA_E_BADARG;
     // Rows are independent: a tensor beyond the fast loader's 31-bit byte offsets (2 GB; StyleGAN2's 1024^2 x 32-channel maps
     // at a few dozen rows) is convolved in sub-batches of rows that fit, each an ordinary launch on the same stream.
     {
@@ -470,10 +471,12 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
         if (d.N > 1 && row_max * d.N >= lim && row_max < lim) {
             int sub = (int)((lim - 1) / row_max);
             const int arep = d.addend && !d.addend_bcast_n && d.addend_rep > 1 ? d.addend_rep : 1;
-            if (arep > 1) {                                  // an addend shared by `arep` consecutive rows: cut at its row boundaries
-                if (d.N % arep) return GA_E_BADARG;
-                sub -= sub % arep;
-                if (sub < arep) return GA_E_UNSUPPORTED;
+            const int drep = d.dact_x && d.dact_rep > 1 ? d.dact_rep : 1;
+            if (arep > 1 || drep > 1) {                      // operands shared by consecutive rows: cut at their row boundaries
+                const long both = (long)arep * drep;         // (a common multiple; the two never meet on one launch in practice)
+                if (d.N % arep || d.N % drep) return GA_E_BADARG;
+                sub -= (int)(sub % both);
+                if (sub < both) return GA_E_UNSUPPORTED;
             }
             for (int n0 = 0; n0 < d.N; n0 += sub) {
                 ga_conv_desc s = d;
@@ -484,7 +487,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
                 s.y = d.y + pout * d.ldy;
                 if (d.addend && !d.addend_bcast_n) s.addend = d.addend + (size_t)(n0 / arep) * d.Ho * d.Wo * d.ldadd;
                 if (d.addend2) s.addend2 = d.addend2 + pout * d.ldadd2;
-                if (d.dact_x) s.dact_x = d.dact_x + pout * d.lddact;
+                if (d.dact_x) s.dact_x = d.dact_x + (size_t)(n0 / drep) * d.Ho * d.Wo * d.lddact;
                 if (d.pro_scale && d.pro_per_row) {
                     s.pro_scale = d.pro_scale + (size_t)n0 * d.C1;
                     s.pro_shift = d.pro_shift + (size_t)n0 * d.C1;

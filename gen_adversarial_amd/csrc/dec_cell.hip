@@ -482,10 +482,12 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
     for (int i = 0; i < TMW; ++i) {
         const size_t gp = pix0 + wb + i * 32 + lrow;
         const size_t n = gp >> gm.lhw;
+        // K cotangents per forward row (act_rep = K): the cell is recomputed from the forward's x, row n / K
+        const size_t xp = d.act_rep > 1 ? (((n / (size_t)d.act_rep) << gm.lhw) + (gp & (size_t)(gm.HW - 1))) : gp;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int k = ks * 16 + 8 * lh;
-            const float* p = d.x + gp * C + k;
+            const float* p = d.x + xp * C + k;
             split8(*reinterpret_cast<const floatx4*>(p), *reinterpret_cast<const floatx4*>(p + 4), xh[i][ks], xl[i][ks]);
             const float* q = d.dout + gp * C + k;
             const float* s = d.pro_scale + n * C + k;
@@ -696,6 +698,7 @@ extern "C" int ga_dec_cell(const ga_dec_cell_desc* dp, void* stream_) {
     if (!d.x || !d.w1_hi || !d.w1_lo || !d.b1 || !d.wd || !d.bd || !d.w2_hi || !d.w2_lo || !d.y) return GA_E_BADARG;
     if (d.backward ? (!d.dout || !d.pro_scale || !d.pro_shift || !d.wd_bwd) : !d.b2) return GA_E_BADARG;
     if (!ga_dec_cell_supported(d.N, d.H, d.W, d.C, d.Hd)) return GA_E_UNSUPPORTED;
+    if (d.act_rep > 1 && (!d.backward || d.N % d.act_rep)) return GA_E_BADARG;
     const void* ptrs[] = {d.x, d.w1_hi, d.w1_lo, d.wd, d.wd_bwd, d.bd, d.w2_hi, d.w2_lo, d.dout, d.pro_scale, d.pro_shift, d.y};
     for (const void* p : ptrs) if (p && !aligned16(p)) return GA_E_ALIGN;
     dc_geom gm;

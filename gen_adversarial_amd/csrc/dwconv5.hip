@@ -100,9 +100,13 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
         }
     };
 
-    auto finish = [&](floatx4 v, const size_t o) __attribute__((always_inline)) {
+    // output row n, offset po inside the row; the act' source is the forward's tensor: row n / act_rep with K cotangents per row
+    const size_t row_out = (size_t)(d.pool2 ? (d.H / 2) * (d.W / 2) : d.H * d.W) * d.C;
+    const int arep = d.act_rep > 1 ? d.act_rep : 1;
+    auto finish = [&](floatx4 v, const int n, const size_t po) __attribute__((always_inline)) {
+        const size_t o = (size_t)n * row_out + po;
         if (d.dact_x) {
-            const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
+            const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (size_t)(n / arep) * row_out + po);
             if (d.dact_act == GA_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(u[e]); v[e] *= sg * (1.0f + u[e] * (1.0f - sg)); }
@@ -127,12 +131,12 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
             for (int j = 0; j < SW; ++j) {
                 const int ww = sx * SW + j;
                 if (ww < tw_n)
-                    finish(acc[j] + bias, (((size_t)(n0 + ni) * d.H + (h0 + hh)) * d.W + (w0 + ww)) * d.C + c);
+                    finish(acc[j] + bias, n0 + ni, ((size_t)(h0 + hh) * d.W + (w0 + ww)) * d.C + c);
             }
         }
     } else {
         // outputs at half resolution: SW must be even; a strip pair (rows 2r, 2r+1) yields SW/2 outputs
-        const int Ho = d.H / 2, Wo = d.W / 2;
+        const int Wo = d.W / 2;
         const int spr = (tw_n + SW - 1) / SW;
         const int nst = nb * (th_n / 2) * spr;
         for (int s = pl; s < nst; s += 32) {
@@ -146,7 +150,7 @@ dwconv5_kernel(const ga_dwconv5_desc d, const int NB, const int TH, const int TW
                 const int ww = sx * SW + j;
                 if (ww < tw_n) {
                     const floatx4 v = a0[j] + a0[j + (SW > 1 ? 1 : 0)] + a1[j] + a1[j + (SW > 1 ? 1 : 0)];
-                    finish(v + bias, (((size_t)(n0 + ni) * Ho + (h0 / 2 + hr)) * Wo + (w0 + ww) / 2) * d.C + c);
+                    finish(v + bias, n0 + ni, ((size_t)(h0 / 2 + hr) * Wo + (w0 + ww) / 2) * d.C + c);
                 }
             }
         }
@@ -223,7 +227,8 @@ __global__ void __launch_bounds__(256, 4) dwconv5_4x4_kernel(const ga_dwconv5_de
             const size_t o = (((size_t)(n0 + ni) * 4 + h) * 4 + w) * d.C + c;
             floatx4 v = acc[w];
             if (d.dact_x) {
-                const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
+                const int na = d.act_rep > 1 ? (n0 + ni) / d.act_rep : n0 + ni;       // K cotangents per forward row
+                const floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + (((size_t)na * 4 + h) * 4 + w) * d.C + c);
                 if (d.dact_act == GA_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(u[e]); v[e] *= sg * (1.0f + u[e] * (1.0f - sg)); }
@@ -248,6 +253,7 @@ extern "C" int ga_dwconv5(const ga_dwconv5_desc* dp, void* stream_) {
     if (d.C % 4) return GA_E_UNSUPPORTED;
     if ((d.up2 || d.pool2) && ((d.H | d.W) & 1)) return GA_E_BADARG;
     if (d.up2 && d.pool2) return GA_E_UNSUPPORTED;
+    if (d.act_rep > 1 && d.N % d.act_rep) return GA_E_BADARG;
     if (!aligned16(d.x) || !aligned16(d.w) || !aligned16(d.y) || (d.bias && !aligned16(d.bias)) ||
         (d.dact_x && !aligned16(d.dact_x))) return GA_E_ALIGN;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);

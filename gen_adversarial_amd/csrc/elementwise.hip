@@ -93,13 +93,15 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
     float* s_hid = sm + d.C;     // Hd
     float* s_part = sm + ((d.C + d.Hd + 3) & ~3);   // fused reduction [PL][C] / FC partials, 16-B aligned
     const int n = blockIdx.x, tid = threadIdx.x;
+    // backward with K cotangents per forward row (act_rep = K): t, gate and hid are the forward's tensors, row n / K
+    const int na = (d.backward && d.act_rep > 1) ? n / d.act_rep : n;
     if (d.t) {
         // fused squeeze / d(gate): channel-quad lanes x pixel lanes, fixed summation order
         const int C4 = d.C >> 2, PL = 256 / C4;
         const int q = tid % C4, pl = tid / C4;
         if (pl < PL) {
             floatx4 acc = {0.f, 0.f, 0.f, 0.f};
-            const float* a = d.t + (size_t)n * d.P * d.C + 4 * q;
+            const float* a = d.t + (size_t)na * d.P * d.C + 4 * q;
             const float* b = d.backward ? d.dout + (size_t)n * d.P * d.C + 4 * q : nullptr;
 #pragma unroll 8
             for (int p = pl; p < d.P; p += PL) {
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
     } else {
         // ds[c] = dgate * gate * (1 - gate)
         for (int c = tid; c < d.C; c += 256) {
-            const float g = d.gate[(size_t)n * d.C + c];
+            const float g = d.gate[(size_t)na * d.C + c];
             const float dg = d.t ? s_in[c] : d.dgate[(size_t)n * d.C + c];
             s_in[c] = dg * g * (1.f - g);
         }
@@ -211,13 +213,13 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             if (tid < d.Hd) {
                 float a2 = 0.f;
                 for (int k = 0; k < nch; ++k) a2 += s_red[tid * nch + k];
-                s_hid[tid] = d.hid[(size_t)n * d.Hd + tid] > 0.f ? a2 : 0.f;
+                s_hid[tid] = d.hid[(size_t)na * d.Hd + tid] > 0.f ? a2 : 0.f;
             }
         } else {
             if (tid < d.Hd) {
                 float a2 = 0.f;
                 for (int c = 0; c < d.C; ++c) a2 += d.w2[(size_t)c * d.Hd + tid] * s_in[c];
-                s_hid[tid] = d.hid[(size_t)n * d.Hd + tid] > 0.f ? a2 : 0.f;
+                s_hid[tid] = d.hid[(size_t)na * d.Hd + tid] > 0.f ? a2 : 0.f;
             }
         }
         __syncthreads();
@@ -226,7 +228,7 @@ __global__ void __launch_bounds__(256) se_excite_kernel(const ga_se_excite_desc 
             float acc = 0.f;
 #pragma unroll 16
             for (int j = 0; j < d.Hd; ++j) acc += d.w1[(size_t)j * d.C + c] * s_hid[j];
-            d.pro_scale[(size_t)n * d.C + c] = d.res_scale * d.gate[(size_t)n * d.C + c];
+            d.pro_scale[(size_t)n * d.C + c] = d.res_scale * d.gate[(size_t)na * d.C + c];
             d.pro_shift[(size_t)n * d.C + c] = acc * invP;
         }
     }
@@ -319,11 +321,14 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
         const int c = (int)(i % d.NL); const long pix = i / d.NL;            // pix = n*hw + p
         const int n = (int)(pix / hw), p = (int)(pix % hw);
         const long zi = d.ldz > 0 ? pix * d.ldz + c : i;
-        const long qpix = d.q_rep > 1 ? (long)(n / d.q_rep) * hw + p : pix;
+        // backward with K cotangents per forward row (act_rep = K): p, eps and mu_q are the forward's tensors, row n / K
+        const int na = (d.backward && d.act_rep > 1) ? n / d.act_rep : n;
+        const long apix = (long)na * hw + p;
+        const long qpix = d.q_rep > 1 ? (long)(na / d.q_rep) * hw + p : apix;
         const float mq = d.mu_q[qpix * d.ldq + c];
-        const float mp = d.p ? d.p[pix * d.ldp + c] : 0.f;
-        const float ls = d.p ? d.p[pix * d.ldp + d.NL + c] : 0.f;
-        const float e = d.eps_nchw ? d.eps[((size_t)n * d.NL + c) * hw + p] : d.eps[i];
+        const float mp = d.p ? d.p[apix * d.ldp + c] : 0.f;
+        const float ls = d.p ? d.p[apix * d.ldp + d.NL + c] : 0.f;
+        const float e = d.eps_nchw ? d.eps[((size_t)na * d.NL + c) * hw + p] : d.eps[apix * d.NL + c];
         const float sig = d.temp * expf(softclamp5(ls));
         const float a = d.alpha, om = d.one_minus_alpha;
         if (!d.backward) {
@@ -356,10 +361,19 @@ __global__ void __launch_bounds__(DML_ROWS) dml_kernel(const ga_dml_desc d, cons
     const int HW = d.H * d.W;
     const int pitch = d.ld + 1;
     const int ldi = d.ld_img > 0 ? d.ld_img : 3;
+    const int arep = (d.backward && d.act_rep > 1) ? d.act_rep : 1;
     for (long base = (long)blockIdx.x * DML_ROWS; base < npix; base += (long)gridDim.x * DML_ROWS) {
         const int nrow = (int)min((long)DML_ROWS, npix - base);
         __syncthreads();
-        if ((d.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(d.logits) & 15) == 0) {   // 16-B global accesses (a quad never straddles two pixels)
+        if (arep > 1) {
+            // K cotangents per forward row: cotangent pixel (n, p) reads the logits of forward pixel (n / K, p); a 128-pixel pass may
+            // straddle rows, so the source pixel is computed per staged row
+            for (int k = threadIdx.x; k < nrow * d.ld; k += DML_ROWS) {
+                const int r = k / d.ld, c = k - r * d.ld;
+                const long px = base + r, n = px / HW;
+                dml_s[r * pitch + c] = d.logits[((n / arep) * HW + (px - n * HW)) * d.ld + c];
+            }
+        } else if ((d.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(d.logits) & 15) == 0) {   // 16-B global accesses (a quad never straddles two pixels)
             const floatx4* src = reinterpret_cast<const floatx4*>(d.logits + base * d.ld);
             const int ld4 = d.ld >> 2;
 #pragma unroll 4
@@ -468,10 +482,13 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const ga_maxpool2_desc d,
         const int wo = (int)(p % Wo); p /= Wo;
         const int ho = (int)(p % Ho); const int n = (int)(p / Ho);
         const size_t base = (((size_t)n * d.H + 2 * ho) * d.W + 2 * wo) * d.C + 4 * c4;
-        const floatx4 a = *reinterpret_cast<const floatx4*>(d.x + base);
-        const floatx4 b = *reinterpret_cast<const floatx4*>(d.x + base + d.C);
-        const floatx4 c = *reinterpret_cast<const floatx4*>(d.x + base + (size_t)d.W * d.C);
-        const floatx4 e = *reinterpret_cast<const floatx4*>(d.x + base + (size_t)d.W * d.C + d.C);
+        // backward with K cotangents per forward row (act_rep = K): the decisions come from the forward's x, row n / K
+        const int na = (d.backward && d.act_rep > 1) ? n / d.act_rep : n;
+        const size_t xb = (((size_t)na * d.H + 2 * ho) * d.W + 2 * wo) * d.C + 4 * c4;
+        const floatx4 a = *reinterpret_cast<const floatx4*>(d.x + xb);
+        const floatx4 b = *reinterpret_cast<const floatx4*>(d.x + xb + d.C);
+        const floatx4 c = *reinterpret_cast<const floatx4*>(d.x + xb + (size_t)d.W * d.C);
+        const floatx4 e = *reinterpret_cast<const floatx4*>(d.x + xb + (size_t)d.W * d.C + d.C);
         if (!d.backward) {
             floatx4 m;
 #pragma unroll
@@ -952,17 +969,20 @@ __global__ void __launch_bounds__(256) image_io_kernel(const ga_image_io_desc d,
             if (c == 0) for (int z = d.C; z < ld; ++z) o[z] = 0.f;      // pad channels of a wider pitch
         }
     } else {
+        // K = cot_rep cotangents per forward row: output (image, k) sums the cotangent rows (image * rep + r) * K + k over r
+        const int K = d.cot_rep > 1 ? d.cot_rep : 1;
         const long total_img = total / d.rep;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_img; i += (long)gridDim.x * 256) {
             const int p = (int)(i % HW); long q = i / HW;
-            const int c = (int)(q % d.C); const int img = (int)(q / d.C);
-            const float x = d.x_nchw[i];
+            const int c = (int)(q % d.C); const int o = (int)(q / d.C);
+            const int img = o / K, k = o - img * K;
+            const float x = d.x_nchw[((size_t)img * d.C + c) * HW + p];
             float acc = 0.f;
             for (int r = 0; r < d.rep; ++r) {
-                const int n = img * d.rep + r;
+                const int nf = img * d.rep + r;             // forward row
                 float v = x;
-                if (d.noise_nchw) v += d.noise_nchw[((size_t)n * d.C + c) * HW + p] * d.noise_coef[n];
-                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[image_px(d, ld, HW, n, p) + c];
+                if (d.noise_nchw) v += d.noise_nchw[((size_t)nf * d.C + c) * HW + p] * d.noise_coef[nf];
+                if (v >= 0.f && v <= 1.f) acc += d.dy_nhwc[image_px(d, ld, HW, nf * K + k, p) + c];
             }
             d.dx_nchw[i] = acc;
         }
@@ -983,7 +1003,9 @@ __global__ void __launch_bounds__(256) interleave2_kernel(const ga_interleave2_d
         if (src) v = *reinterpret_cast<const floatx4*>(src + (((size_t)n * Hh + (h >> 1)) * Wh + (w >> 1)) * (d.lds > 0 ? d.lds : d.C) + 4 * q);
         const size_t o = (size_t)p * d.C + 4 * q;
         if (d.dact_x) {
-            floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + o);
+            // K cotangents per forward row (dact_rep = K): the act' source is the forward's tensor, row n / K
+            const size_t od = d.dact_rep > 1 ? ((((size_t)(n / d.dact_rep) * d.H + h) * d.W + w) * d.C + 4 * q) : o;
+            floatx4 u = *reinterpret_cast<const floatx4*>(d.dact_x + od);
             floatx4 ds = {1.f, 1.f, 1.f, 1.f};
             if (d.dact_prelu) {
                 ds = *reinterpret_cast<const floatx4*>(d.dact_scale + 4 * q);
@@ -1153,6 +1175,7 @@ extern "C" int ga_se_excite(const ga_se_excite_desc* d, void* s) {
     if (!d->backward && !d->m && !d->t) return GA_E_BADARG;
     if (d->backward && ((!d->dgate && !d->t) || !d->pro_scale || !d->pro_shift || d->P <= 0)) return GA_E_BADARG;
     if (d->out && (d->backward || !d->t || !aligned16(d->out) || (d->skip && !aligned16(d->skip)))) return GA_E_BADARG;
+    if (d->act_rep > 1 && (!d->backward || !d->t || d->N % d->act_rep)) return GA_E_BADARG;
     size_t lds = (size_t)(d->C + d->Hd + 4 + 256) * sizeof(float);     // + [Hd][chunks] partials of the FC phases
     if (d->Hd > 256) return GA_E_UNSUPPORTED;
     if (d->t) {
@@ -1197,6 +1220,7 @@ extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
     if (!d->backward && !d->z) return GA_E_BADARG;
     if (d->backward && (!d->dz || (d->q_rep > 1 ? !d->dmu_q_rows : !d->dmu_q) || (d->p && !d->dp))) return GA_E_BADARG;
     if (d->q_rep > 1 && d->N % d->q_rep) return GA_E_BADARG;
+    if (d->act_rep > 1 && (!d->backward || d->N % d->act_rep || (d->q_rep > 1 && (d->N / d->act_rep) % d->q_rep))) return GA_E_BADARG;
     const long total = (long)d->N * d->h * d->w * d->NL;
     hipLaunchKernelGGL(sampler_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();
@@ -1209,6 +1233,7 @@ extern "C" int ga_dml_mean(const ga_dml_desc* d, void* s) {
     if (d->ld < d->nmix * 10 || (d->ld_img != 0 && d->ld_img < 3)) return GA_E_BADARG;
     if (!d->backward && !d->img_nchw && !d->img_nhwc) return GA_E_BADARG;
     if (d->backward && (!d->dlogits || (!d->dimg_nhwc && !d->dimg_nchw))) return GA_E_BADARG;
+    if (d->act_rep > 1 && (!d->backward || d->N % d->act_rep)) return GA_E_BADARG;
     const long npix = (long)d->N * d->H * d->W;
     const size_t lds = (size_t)DML_ROWS * (d->ld + 1) * sizeof(float);
     if (lds > 64 * 1024) return GA_E_UNSUPPORTED;
@@ -1225,6 +1250,7 @@ extern "C" int ga_maxpool2(const ga_maxpool2_desc* d, void* s) {
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && !d->y) return GA_E_BADARG;
     if (d->backward && (!d->dy || !d->dx)) return GA_E_BADARG;
+    if (d->act_rep > 1 && (!d->backward || d->N % d->act_rep)) return GA_E_BADARG;
     const long total4 = (long)d->N * (d->H / 2) * (d->W / 2) * (d->C / 4);
     hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, total4);
     return check_launch();
@@ -1381,6 +1407,7 @@ extern "C" int ga_image_io(const ga_image_io_desc* d, void* s) {
     if (d->backward && (!d->dy_nhwc || !d->dx_nchw)) return GA_E_BADARG;
     if (d->ld != 0 && d->ld < d->C) return GA_E_BADARG;
     if (d->s2d && ((d->H | d->W) & 1)) return GA_E_BADARG;
+    if (d->cot_rep > 1 && (!d->backward || d->N % (d->rep * d->cot_rep))) return GA_E_BADARG;
     const long total = (long)d->N * d->C * d->H * d->W;
     hipLaunchKernelGGL(image_io_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();

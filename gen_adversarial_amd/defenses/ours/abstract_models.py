@@ -70,8 +70,51 @@ class _EngineFn(torch.autograd.Function):
         return eng.dx.clone(), None, None, None
 
 
+class _EngineJacobian:
+    """Per-class input gradients of the EoT-mean logits from ONE forward and ceil(n_columns / K) backward replays (the engine's
+    K-cotangent backward plan).  `logits`: (B, n) EoT means; `grads()`: (B, n_columns, 3, H, W) with
+    d mean_logit[b, classes[b, j]] / d x_b — what DeepFool (src/attacks/untargeted.py:526-560) and FAB (:605-635) obtain by one
+    `.backward(retain_graph=True)` per class."""
+
+    def __init__(self, owner, eng: Engine, x: torch.Tensor, rep: int, classes):
+        self.owner, self.eng, self.rep, self.classes = owner, eng, rep, classes
+        self.x = x.detach().clone()
+        eng.x_in.copy_(self.x)
+        owner._fill_noise(eng)
+        eng.forward()
+        eng.version += 1
+        self.version, self.noise = eng.version, owner._snapshot_noise(eng)
+        self.logits = eng.logits.view(x.shape[0], rep, -1).mean(dim=1)
+
+    def grads(self) -> torch.Tensor:
+        eng, B, rep, K = self.eng, self.x.shape[0], self.rep, self.eng.cot_rep
+        if eng.version != self.version:                      # another forward ran on this engine since: same inputs, same noise
+            eng.x_in.copy_(self.x)
+            self.owner._restore_noise(eng, self.noise)
+            eng.forward()
+            eng.version += 1
+            self.version = eng.version
+        n = self.logits.shape[1]
+        cols = self.classes if self.classes is not None else torch.arange(n, device=self.x.device).expand(B, n)
+        out = []
+        dl = eng.dlogits.view(B, rep, K, n)                  # cotangent k of defender row (b, j) at row (b * rep + j) * K + k
+        for j0 in range(0, cols.shape[1], K):
+            idx = cols[:, j0:j0 + K]                         # (B, k) class of cotangent k for image b
+            k = idx.shape[1]
+            dl.zero_()
+            # d mean_j logits[b, j, c] / d logits[b, j, c] = 1 / rep for every replica j
+            dl[:, :, :k].scatter_(3, idx.view(B, 1, k, 1).expand(B, rep, k, 1), 1.0 / rep)
+            eng.backward()
+            out.append(eng.dx.view(B, K, *eng.dx.shape[1:])[:, :k].clone())
+        return torch.cat(out, dim=1)
+
+
 class _EngineOwner:
     """Engines are built lazily per (rows, rep) and share one device copy of the folded weights."""
+
+    # cotangent rows one K-cotangent backward replay may carry (rows x K): the 32-row reference protocol gets K = 16, i.e. all
+    # 10 DeepFool classes in one replay and the 100 classes of the ids experiment in 7 instead of 100
+    jacobian_cot_rows = 512
 
     def _init_engines(self, device):
         self.device = device
@@ -82,10 +125,11 @@ class _EngineOwner:
         self._store = WeightStore(dev)
         self._fixed_noise = None
 
-    def _engine(self, rows: int, rep: int, with_noise: bool = True) -> Engine:
-        key = (rows, rep, with_noise)
+    def _engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1) -> Engine:
+        key = (rows, rep, with_noise) if cot_rep == 1 else (rows, rep, with_noise, cot_rep)
         if key not in self._engines:
-            self._engines[key] = self._make_engine(rows, rep, with_noise)
+            self._engines[key] = (self._make_engine(rows, rep, with_noise) if cot_rep == 1 else
+                                  self._make_engine(rows, rep, with_noise, cot_rep=cot_rep))
         eng = self._engines[key]
         alphas = self._current_alphas()
         if alphas is not None:
@@ -128,6 +172,26 @@ class _EngineOwner:
             eng.noise.copy_(snap[1][0])
             eng.noise_coef.copy_(snap[1][1])
 
+    supports_class_jacobian = False          # owners whose _make_engine takes cot_rep (NVAE + VGG defender, VGG classifier)
+
+    def class_jacobian_rows(self, batch: torch.Tensor, rep: int, classes=None):
+        """_EngineJacobian of (B,3,H,W) images under EoT `rep`, or None when this owner has no K-cotangent plan (callers then
+        fall back to one autograd backward per class)."""
+        if not self.supports_class_jacobian or getattr(self, 'bpda', False):
+            return None
+        batch = batch.to(self.device, dtype=torch.float32).contiguous()
+        rows = batch.shape[0] * rep
+        n_cols = classes.shape[1] if classes is not None else None
+        K = max(1, self.jacobian_cot_rows // rows)
+        if n_cols is not None:
+            K = min(K, n_cols)
+        if K < 2:
+            return None
+        eng = self._engine(rows, rep, True, cot_rep=K)
+        if tuple(batch.shape[2:]) != tuple(eng.resolution[1:]):
+            raise ValueError(f'expected {eng.resolution[1]}x{eng.resolution[2]} images, got {tuple(batch.shape[2:])}')
+        return _EngineJacobian(self, eng, batch, rep, classes)
+
     def _run(self, batch: torch.Tensor, rep: int, want_purified: bool, with_noise: bool = True):
         if batch.dim() != 4 or batch.shape[1] != 3:
             raise ValueError('expected a (B, 3, H, W) image batch')
@@ -165,11 +229,20 @@ class BaseClassificationModel(ABC, _EngineOwner):
     def input_resolution(self) -> int:
         return getattr(self, 'image_size', 64)
 
-    def _make_engine(self, rows: int, rep: int, with_noise: bool = True) -> Engine:
+    @property
+    def supports_class_jacobian(self) -> bool:
+        from ...vgg_spec import VggSpec
+        return isinstance(self.classifier.spec, VggSpec)
+
+    def _make_engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1) -> Engine:
         w = self.classifier
         r = self.input_resolution()
         return Engine(None, None, (3, r, r), w.state_dict, w.spec, rows=rows, rep=rep, alphas=[], device=self.device,
-                      store=self._store)
+                      store=self._store, cot_rep=cot_rep)
+
+    def class_jacobian(self, batch: torch.Tensor, classes=None):
+        self.image_size = batch.shape[-1]
+        return self.class_jacobian_rows(batch, 1, classes)
 
     def forward_rows(self, batch: torch.Tensor, rep: int = 1) -> torch.Tensor:
         return self._run(batch, rep, False)[0]
@@ -222,3 +295,6 @@ class MLVGMDefenseModel(ABC, _EngineOwner):
 
     def __call__(self, batch: torch.Tensor, preds_only: bool = True):
         return self.forward_rows(batch, 1, preds_only)
+
+    def class_jacobian(self, batch: torch.Tensor, classes=None):
+        return self.class_jacobian_rows(batch, 1, classes)

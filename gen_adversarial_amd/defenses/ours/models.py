@@ -62,13 +62,18 @@ class NVAEDefenseModel(MLVGMDefenseModel, torch.nn.Module):
     def load_autoencoder(self, model_path: str, device: str) -> NVAEWeights:
         return load_NVAE(model_path, device, self.temperature)
 
-    def _make_engine(self, rows: int, rep: int, with_noise: bool = True) -> Engine:
+    @property
+    def supports_class_jacobian(self) -> bool:
+        from ...vgg_spec import VggSpec
+        return isinstance(self.classifier.classifier.spec, VggSpec)
+
+    def _make_engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1) -> Engine:
         ae, clf = self.autoencoder, self.classifier.classifier
         return Engine(ae.state_dict, ae.config, ae.resolution, clf.state_dict, clf.spec, rows=rows, rep=rep,
                       alphas=self.interpolation_alphas, temperature=self.temperature,
                       noise_eps=self.eps if with_noise else 0.0, blur=self.blur_input and with_noise,
                       share_encoder=True,      # EoT replicas share the encoder pass whenever no input noise is drawn
-                      device=self.device, store=self._store)
+                      device=self.device, store=self._store, cot_rep=cot_rep)
 
 
 def _next(name, what):

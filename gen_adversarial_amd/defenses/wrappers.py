@@ -27,3 +27,10 @@ class EoTWrapper(torch.nn.Module):
         x = x.repeat(self.eot_steps, 1, 1, 1)
         preds = self.model(x)
         return torch.mean(preds, dim=0, keepdim=True)
+
+    def class_jacobian(self, x: torch.Tensor, classes=None):
+        """ONE forward + ceil(columns / K) backward replays for the per-class input gradients of the EoT-mean logits (the HIP
+        engine's K-cotangent plan), or None when the wrapped model has none: attacks.l2_attacks.ClassJacobian then takes one
+        autograd backward per class, like the reference (src/attacks/untargeted.py:526-560, :605-635)."""
+        fast = getattr(self.model, 'class_jacobian_rows', None)
+        return fast(x, self.eot_steps, classes) if fast is not None else None

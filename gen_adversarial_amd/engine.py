@@ -47,7 +47,11 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,
                  device: str = 'cuda:0', need_backward: bool = True, dry_run: bool = False,
                  store: Optional[WeightStore] = None, precision: str = 'bf16x3', blur: bool = False,
-                 share_encoder: bool = False):
+                 share_encoder: bool = False, cot_rep: int = 1):
+        """cot_rep = K > 1: the backward plan takes K cotangents per forward row in ONE replay (the per-class
+        backward loops of DeepFool / FAB, src/attacks/untargeted.py:526-560, :605-635).  `dlogits` is then [rows * K, classes]
+        (cotangent k of defender row r at row r * K + k) and `dx` [images * K, 3, H, W] (gradient k of image b at row b * K + k);
+        every saved activation is read by its K cotangent rows, nothing is recomputed or copied."""
         if rows % rep:
             raise ValueError('rows must be a multiple of the EoT repeat')
         self.device = torch.device(device)
@@ -77,6 +81,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0 and nvae_sd is not None
         self.enc_rows = rows // rep if self.share_encoder else rows
         self.need_backward = need_backward
+        if cot_rep < 1 or (cot_rep > 1 and not (self.has_nvae or isinstance(vgg_spec, VggSpec))):
+            raise ValueError('cot_rep > 1 (K-cotangent backward) is built for the NVAE + VGG defender and the VGG classifier')
+        self.cot_rep = int(cot_rep)
         self.bytes = 0
         self.acts = {}                       # name -> Act (debugging / tests)
         self.version = 0                     # bumped by callers after each forward (stale-backward detection)
@@ -108,7 +115,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         # draw runs once per image (see Engine.__init__); builders that support it read share_encoder / enc_rows
         self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0
         self.enc_rows = rows // rep if self.share_encoder else rows
-        self.need_backward, self.image_s2d = need_backward, False
+        self.need_backward, self.image_s2d, self.cot_rep = need_backward, False, 1
         self.bytes, self.acts, self.version, self._sampler_descs, self._keep = 0, {}, 0, [], []
         self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
@@ -166,6 +173,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         if dact_x is not None:
             d.dact_x, d.lddact = _ptr(dact_x), dact_x.shape[-1]
             d.dact_scale, d.dact_shift, d.dact_act = _ptr(dact_scale), _ptr(dact_shift), dact_act
+            if dact_x.shape[0] != x.shape[0]:           # K cotangent rows per saved activation row (K-cotangent backward plan)
+                assert dact_x.shape[0] * self.cot_rep == x.shape[0], (name, tuple(dact_x.shape), tuple(x.shape), self.cot_rep)
+                d.dact_rep = self.cot_rep
         d.N, d.Hi, d.Wi, d.Ho, d.Wo = N, Hi, Wi, Ho, Wo
         d.KH, d.KW = (KH or K), (KW or K)
         d.sn, d.sd, d.pad = sn, sd, pad
@@ -231,6 +241,9 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         il.y, il.N, il.H, il.W, il.C = _ptr(target.g), n, 2 * h, 2 * w, target.c
         il.dact_x, il.dact_scale, il.dact_shift, il.dact_act = _ptr(dact_x), _ptr(dact_scale), _ptr(dact_shift), dact_act
         il.dact_prelu = int(dact_prelu)
+        if dact_x is not None and dact_x.shape[0] != n:
+            assert dact_x.shape[0] * self.cot_rep == n, (name, tuple(dact_x.shape), n)
+            il.dact_rep = self.cot_rep
         if target.g_written:
             il.addend = _ptr(target.g)
         self.bwd.add(il, name + '.interleave')
@@ -266,10 +279,11 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
 
     def se_backward(self, name, dout: torch.Tensor, t: Act, wts, gate, hid, P, res_scale=None):
         """emits d(gate) reduction + excite backward; returns the per-row prologue (scale, shift) for the next GEMM."""
-        n, c = t.n, t.c
+        n, c = dout.shape[0], t.c                           # cotangent rows (t.n * cot_rep)
         ps = self.scratch((n, c), f'ps{c}')
         pb = self.scratch((n, c), f'pb{c}')
         e = L.SeExciteDesc()
+        e.act_rep = self.cot_rep
         e.t, e.dout = _ptr(t.t), _ptr(dout)                 # fused d(gate) reduction + excite backward
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
         e.hid, e.gate, e.pro_scale, e.pro_shift = _ptr(hid), _ptr(gate), _ptr(ps), _ptr(pb)
@@ -309,7 +323,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
         self.x_in = self.alloc((R // self.rep, 3, H, H))                    # NCHW images in [0,1]
         self.noise = self.alloc((R, 3, H, H)) if self.noise_eps != 0.0 else None
         self.noise_coef = self.alloc((R,)) if self.noise_eps != 0.0 else None
-        self.dx = self.alloc((R // self.rep, 3, H, H))
+        self.dx = self.alloc((R // self.rep * self.cot_rep, 3, H, H))      # [image * K + k]: gradient k of image `image`
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
 
         # optional Gaussian blur of the input (abstract_models.py:145-159): deterministic, so it is applied to the B
@@ -322,7 +336,7 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
             g = torch.exp(-xs.pow(2) / 2.0)
             taps = self.devd(f'blur_taps_{k}', lambda: {'g': (g / g.sum()).float()})['g']
             x_src = self.alloc((R // self.rep, 3, H, H))
-            dx_dst = self.alloc((R // self.rep, 3, H, H))
+            dx_dst = self.alloc((R // self.rep * self.cot_rep, 3, H, H))
             # sigma 1: taps beyond 12 pixels are < 1e-31 of the peak (the 255-tap kernel of 256-px images has 25 that matter);
             # planes above ~90 px do not fit LDS and run as two passes through `tmp`
             tmp = self.alloc((R // self.rep, 3, H, H)) if (2 * H * H + k) * 4 > 64 * 1024 else None
@@ -333,7 +347,8 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
 
             def bwd_blur():
                 b = L.BlurDesc()
-                b.x, b.y, b.taps, b.planes, b.H, b.W, b.k, b.backward = _ptr(dx_dst), _ptr(self.dx), _ptr(taps), (R // self.rep) * 3, H, H, k, 1
+                b.x, b.y, b.taps, b.planes, b.H, b.W, b.k, b.backward = (_ptr(dx_dst), _ptr(self.dx), _ptr(taps),
+                                                                         (R // self.rep) * self.cot_rep * 3, H, H, k, 1)
                 b.radius, b.tmp = min(12, k // 2), _ptr(tmp)
                 self.bwd.add(b, 'gauss_blur^T')
             self._bwd_steps.append(bwd_blur)
@@ -353,7 +368,8 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
             b = L.ImageIoDesc()
             b.x_nchw, b.noise_nchw, b.noise_coef = _ptr(x_src), _ptr(self.noise), _ptr(self.noise_coef)
             b.dy_nhwc, b.dx_nchw = _ptr(x0.g), _ptr(dx_dst)
-            b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = R0, 3, H, H, rep0, 1, IMG_LD, int(self.image_s2d)
+            b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = R0 * self.cot_rep, 3, H, H, rep0, 1, IMG_LD, int(self.image_s2d)
+            b.cot_rep = self.cot_rep
             self.bwd.add(b, 'image_in^T')
         self._bwd_steps.append(bwd_image)
 
@@ -380,7 +396,8 @@ class Engine(NvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransB
             if hp == self.resolution[1]:                    # same size in and out (a face_pool to another size has no identity)
                 b = L.ImageIoDesc()
                 b.x_nchw, b.dy_nhwc, b.dx_nchw = _ptr(self.x_in), _ptr(pg.g), _ptr(self.dx)
-                b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = self.rows, 3, hp, hp, self.rep, 1, IMG_LD, s2d
+                b.N, b.C, b.H, b.W, b.rep, b.backward, b.ld, b.s2d = self.rows * self.cot_rep, 3, hp, hp, self.rep, 1, IMG_LD, s2d
+                b.cot_rep = self.cot_rep
                 self.bpda = L.Plan()
                 self.bpda.add(b, 'bpda_identity^T')
                 self.bpda.finalize()

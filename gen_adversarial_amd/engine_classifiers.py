@@ -50,7 +50,9 @@ class ClassifierBuilder:
 
                 def bwd(src=src, pl=pl):
                     b = L.MaxpoolDesc()
-                    b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = _ptr(src.t), _ptr(pl.g), _ptr(src.g), R, src.h, src.w, src.c, 1
+                    b.x, b.dy, b.dx, b.N, b.H, b.W, b.C, b.backward = (_ptr(src.t), _ptr(pl.g), _ptr(src.g), R * self.cot_rep,
+                                                                       src.h, src.w, src.c, 1)
+                    b.act_rep = self.cot_rep
                     self.bwd.add(b, pl.name + '^T')
                     src.g_written = True
                 self._bwd_steps.append(bwd)
@@ -70,7 +72,7 @@ class ClassifierBuilder:
 
         def bwd_head():
             self.grad_conv('vgg.head2^T', out.g, head['w_out_bwd'], h1, K=1, dact_x=h1.t, dact_act=L.GA_ACT_RELU)
-            gflat = feat.g.view(R, 1, 1, f * f * feat.c)
+            gflat = feat.g.view(R * self.cot_rep, 1, 1, f * f * feat.c)
             assert not feat.g_written
             self.conv(self.bwd, 'vgg.head1^T', h1.g, head['w_head_bwd'], gflat, K=1, dact_x=feat_flat, dact_act=L.GA_ACT_RELU)
             feat.g_written = True

@@ -65,7 +65,9 @@ class WeightStore:
 
 
 class Act:
-    """An NHWC activation buffer plus its (lazily allocated) gradient buffer."""
+    """An NHWC activation buffer plus its (lazily allocated) gradient buffer.  With K cotangents per forward row
+    (Engine(cot_rep=K): the K-cotangent backward plan) the gradient buffer has n * K rows, cotangent k of forward row r at row
+    r * K + k; the backward ops read the saved activation of cotangent row m at row m // K (`act_rep` / `dact_rep` of ga_ops.h)."""
 
     def __init__(self, eng: "Engine", n, h, w, c, name=''):
         self.eng, self.n, self.h, self.w, self.c, self.name = eng, n, h, w, c, name
@@ -77,7 +79,7 @@ class Act:
     @property
     def g(self) -> torch.Tensor:
         if self._g is None:
-            self._g = self.eng.alloc((self.n, self.h, self.w, self.c))
+            self._g = self.eng.alloc((self.n * getattr(self.eng, 'cot_rep', 1), self.h, self.w, self.c))
         return self._g
 
 

@@ -44,7 +44,7 @@ class NvaeBuilder:
 
         def backward():
             ps, pb = self.se_backward(p, out.g, t2, wts, gate, hid, ho * wo)
-            dt1 = self.scratch((n, ho, wo, cell.cout), 'enc_dt1')
+            dt1 = self.scratch((out.g.shape[0], ho, wo, cell.cout), 'enc_dt1')
             self.conv(self.bwd, p + '.conv2^T', out.g, wts['w2_bwd'], dt1, K=3, pad=1,
                       pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t1.t, dact_act=L.GA_ACT_SILU)
             if cell.down:       # both stride-2 transposes by sub-pixel decomposition (stride-1 convs on the matrix path)
@@ -112,25 +112,27 @@ class NvaeBuilder:
             self.fwd.add(a, p + '.merge')
 
         def backward():
+            nc = out.g.shape[0]                                 # cotangent rows: n * cot_rep
             ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W)
-            dt1 = self.scratch((n, h, w, hid_c), 'dec_dt1')
+            dt1 = self.scratch((nc, h, w, hid_c), 'dec_dt1')
             if fused:
                 b = fused_desc(1)
                 b.dout, b.pro_scale, b.pro_shift, b.y = _ptr(out.g), _ptr(ps), _ptr(pb), _ptr(dt1)
+                b.N, b.act_rep = nc, self.cot_rep
                 self.bwd.add(b, p + '.cell^T')
             else:
-                dt2 = self.scratch((n, H, W, hid_c), 'dec_dt2')
+                dt2 = self.scratch((nc, H, W, hid_c), 'dec_dt2')
                 self.conv(self.bwd, p + '.pw2^T', out.g, wts['w2_bwd'], dt2, K=1,
                           pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t2.t, dact_act=L.GA_ACT_SILU)
                 b = L.DwDesc()
                 b.x, b.w, b.dact_x, b.y = _ptr(dt2), _ptr(wts['wd_bwd']), _ptr(t1.t), _ptr(dt1)
-                b.N, b.H, b.W, b.C, b.dact_act, b.pool2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
+                b.N, b.H, b.W, b.C, b.dact_act, b.pool2, b.act_rep = nc, H, W, hid_c, L.GA_ACT_SILU, int(up), self.cot_rep
                 self.bwd.add(b, p + '.dw5^T')
             self.grad_conv(p + '.pw1^T', dt1, wts['w1_bwd'], x, K=1, primary=None if up else out.g)
             if up:
-                dsl = self.scratch((n, h, w, cell.cout), 'dec_dsl')
+                dsl = self.scratch((nc, h, w, cell.cout), 'dec_dsl')
                 bl = L.BilinearBwdDesc()
-                bl.dhigh, bl.dlow, bl.N, bl.h, bl.w, bl.C, bl.accumulate = _ptr(out.g), _ptr(dsl), n, h, w, cell.cout, 0
+                bl.dhigh, bl.dlow, bl.N, bl.h, bl.w, bl.C, bl.accumulate = _ptr(out.g), _ptr(dsl), nc, h, w, cell.cout, 0
                 self.bwd.add(bl, p + '.bilinear^T')
                 self.grad_conv(p + '.skip^T', dsl, wts['ws_bwd'], x, K=1)
         self._bwd_steps.append(backward)
@@ -238,14 +240,14 @@ class NvaeBuilder:
         dm.logits, dm.ld, dm.nmix, dm.img_nchw, dm.img_nhwc = _ptr(logits.t), LO, spec.num_mixtures, _ptr(self.purified), _ptr(img.t)
         dm.N, dm.H, dm.W, dm.backward, dm.ld_img = R, H, H, 0, IMG_LD
         self.fwd.add(dm, 'dml_mean')
-        self.dpurified = self.alloc((R, 3, H, H))    # optional external gradient on the purified image (NCHW)
+        self.dpurified = self.alloc((R * self.cot_rep, 3, H, H))    # optional external gradient on the purified image (NCHW)
         purified_img = img
 
         def bwd_dml():
             b = L.DmlDesc()
             b.logits, b.ld, b.nmix, b.dimg_nhwc, b.dlogits = _ptr(logits.t), LO, spec.num_mixtures, _ptr(img.g), _ptr(logits.g)
             b.dimg_nchw = _ptr(self.dpurified)
-            b.N, b.H, b.W, b.backward, b.ld_img = R, H, H, 1, IMG_LD
+            b.N, b.H, b.W, b.backward, b.ld_img, b.act_rep = R * self.cot_rep, H, H, 1, IMG_LD, self.cot_rep
             self.bwd.add(b, 'dml_mean^T')
             self.grad_conv('to_logits^T', logits.g, tl['w_bwd'], post_out, K=3, pad=1, dact_x=post_out.t, dact_act=L.GA_ACT_ELU)
         self._bwd_steps.append(bwd_dml)
@@ -275,12 +277,13 @@ class NvaeBuilder:
         d.eps, d.eps_nchw, d.dz = _ptr(eps), 1, _ptr(z.g)
         d.q_rep = q_rep
         rows_grad = None
+        nc = z.n * self.cot_rep                                 # cotangent rows
         if q_rep > 1:
-            rows_grad = self.scratch((z.n, z.h, z.w, z.c), 'dmu_q_rows')
+            rows_grad = self.scratch((nc, z.h, z.w, z.c), 'dmu_q_rows')
             d.dmu_q_rows = _ptr(rows_grad)
         else:
             d.dmu_q = _ptr(muq.g)
-        d.N, d.h, d.w, d.NL, d.ldz = z.n, z.h, z.w, self.spec.num_latent, z.c
+        d.N, d.h, d.w, d.NL, d.ldz, d.act_rep = nc, z.h, z.w, self.spec.num_latent, z.c, self.cot_rep
         d.alpha, d.one_minus_alpha, d.temp, d.backward = alpha, 1.0 - alpha, self.temperature, 1
         self._sampler_descs.append((d, [i for i, e in enumerate(self.eps) if e is eps][0]))
         self.bwd.add(d, name)
@@ -291,7 +294,10 @@ class NvaeBuilder:
     def rep_sum(self, name, x_rows: torch.Tensor, target: Act, rep: int):
         """target.g (+)= sum over the `rep` replicas of x_rows (gradient of a tensor shared by the EoT replicas)"""
         r = L.RepSumDesc()
-        r.x, r.y, r.rows, r.inner, r.rep = _ptr(x_rows), _ptr(target.g), x_rows.shape[0], x_rows[0].numel(), rep
+        # x_rows is [forward rows][K cotangents][...]: summing the `rep` replicas of an image keeps (image, k) apart when the K
+        # cotangents count as part of the row
+        K = self.cot_rep
+        r.x, r.y, r.rows, r.inner, r.rep = _ptr(x_rows), _ptr(target.g), x_rows.shape[0] // K, x_rows[0].numel() * K, rep
         r.accumulate = int(target.g_written)
         self.bwd.add(r, name)
         target.g_written = True

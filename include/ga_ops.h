@@ -89,7 +89,8 @@ typedef struct ga_conv_desc {
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
     long ws_floats;
     unsigned x_bytes, x2_bytes, w_bytes;   /* filled in by ga_conv2d (buffer extents); callers leave them 0 */
-    unsigned _reserved;
+    int dact_rep;                          /* > 1: dact_x has N/dact_rep rows, output row n reads dact_x row n / dact_rep (K cotangents
+                                              per saved forward activation: the K-cotangent backward plans, see "act_rep" below) */
     const void* w_hi;                      /* optional: w split as bf16 hi + lo, both [Cout][KH*KW*(C1+C2)] (ga_split_bf16). */
     const void* w_lo;                      /* When given and the shape allows, the contraction runs as 3 bf16 MFMAs per
                                               product on the bf16 matrix cores (~2e-5 relative), else exact fp32 MFMA. */
@@ -114,6 +115,8 @@ typedef struct ga_dwconv5_desc {
     float* y;            /* [N,Ho,Wo,C]; Ho = H/2 if pool2 else H */
     int N, H, W, C;      /* H,W = resolution at which the 5x5 window slides */
     int pro_act, dact_act, up2, pool2;
+    int act_rep;         /* > 1: dact_x has N/act_rep rows, row n reads dact_x row n / act_rep */
+    int _reserved;
 } ga_dwconv5_desc;
 int ga_dwconv5(const ga_dwconv5_desc* d, void* stream);
 
@@ -151,6 +154,9 @@ typedef struct ga_se_excite_desc {
      *   out[n,p,c] = skip[n,p,c] + res_scale * gate[n,c] * t[n,p,c]      (skip may be NULL)
      * — one launch and one pass over t less per cell; same expression, bitwise the result of the separate launch */
     const float* skip; float* out;
+    /* backward, fused form: act_rep > 1 = K cotangents per forward row.  N counts cotangent rows (dout, pro_scale, pro_shift have N
+     * rows); t, gate and hid are the forward's [N/act_rep, ...] tensors and cotangent row n reads their row n / act_rep. */
+    int act_rep; int _reserved;
 } ga_se_excite_desc;
 int ga_se_excite(const ga_se_excite_desc* d, void* stream);
 
@@ -193,7 +199,9 @@ typedef struct ga_sampler_desc {
     float* dmu_q_rows;
     int ldz;           /* channel pitch of z and dz (0: NL).  Latent tensors padded to a multiple of 8 channels (zeros) keep the convs
                           around them on the split-bf16 kernels; dmu_q_rows then has pitch ldq like dmu_q */
-    int _reserved;
+    int act_rep;       /* backward, > 1: K cotangents per forward row.  N counts cotangent rows (dz, dp, dmu_q / dmu_q_rows); p and eps
+                          are the forward's [N/act_rep, ...] tensors read at row n / act_rep, mu_q at row (n / act_rep) / q_rep.  dmu_q
+                          is then written per cotangent row only through dmu_q_rows when q_rep > 1 (as without act_rep) */
 } ga_sampler_desc;
 int ga_sampler_mix(const ga_sampler_desc* d, void* stream);
 
@@ -210,7 +218,8 @@ typedef struct ga_dml_desc {
     int N, H, W; int backward;
     int ld_img;               /* channel pitch of img_nhwc / dimg_nhwc (0 = 3).  With a pitch > 3 the forward also zeroes the
                                  pad channels, so that the image can feed a vectorised conv as a ld_img-channel tensor */
-    int _reserved;
+    int act_rep;              /* backward, > 1: N counts cotangent rows (dimg_*, dlogits); logits has N/act_rep rows, row n reads
+                                 row n / act_rep */
 } ga_dml_desc;
 int ga_dml_mean(const ga_dml_desc* d, void* stream);
 
@@ -218,6 +227,7 @@ int ga_dml_mean(const ga_dml_desc* d, void* stream);
  * the first maximal element in (h,w) scan order. */
 typedef struct ga_maxpool2_desc {
     const float* x; float* y; const float* dy; float* dx; int N, H, W, C; int backward;
+    int act_rep;      /* backward, > 1: N counts cotangent rows (dy, dx); x has N/act_rep rows, row n reads x row n / act_rep */
 } ga_maxpool2_desc;
 int ga_maxpool2(const ga_maxpool2_desc* d, void* stream);
 
@@ -363,9 +373,19 @@ typedef struct ga_dec_cell_desc {
     const float* dout; const float* pro_scale; const float* pro_shift;
     float* y;
     int N, H, W, C, Hd; int backward;
+    int act_rep;              /* backward, > 1: N counts cotangent rows (dout, pro_scale, pro_shift, y); x has N/act_rep rows, cotangent
+                                 row n recomputes from x row n / act_rep */
+    int _reserved;
 } ga_dec_cell_desc;
 int ga_dec_cell(const ga_dec_cell_desc* d, void* stream);
 int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_dec_cell takes the shape */
+
+/* On-box peak microbenchmarks for bench.py's roofline.frac_of_measured_peak; not part of the path.
+ * ga_microbench_hbm_copy: dst = src, n_floats % 4 == 0, 16 B per lane (2 * 4 * n_floats bytes of traffic per call).
+ * ga_microbench_mfma_bf16: a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, `blocks` workgroups of 4 waves;
+ *   flops per call = blocks * 4 * iters * 8 * (2 * 32 * 32 * 16); out: >= blocks * 256 floats (keeps the accumulators live). */
+int ga_microbench_hbm_copy(const float* src, float* dst, long n_floats, void* stream);
+int ga_microbench_mfma_bf16(float* out, int blocks, int iters, void* stream);
 
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
@@ -406,6 +426,11 @@ typedef struct ga_image_io_desc {
     int s2d;                  /* 1: space-to-depth layout — y_nhwc is [N, H/2, W/2, 4*ld], pixel (h, w) channel c at
                                  [n, h/2, w/2, ((h&1)*2 + (w&1))*ld + c]: a stride-2 conv over the image becomes a stride-1
                                  conv over this tensor (ResNet's 7x7/2 stem = 4x4 taps x 4*ld channels) */
+    int cot_rep;              /* backward, > 1: K cotangents per forward row.  dy_nhwc has N rows, cotangent row r*K + k belonging to
+                                 forward row r = image*rep + j; dx_nchw is [(N/K/rep)*K, C, H, W] with
+                                 dx[image*K + k] = sum_j dy[(image*rep + j)*K + k] * 1[0 <= pre(image, j) <= 1];
+                                 x_nchw / noise are the forward's ([N/K/rep] images, [N/K] noise rows) */
+    int _reserved;
 } ga_image_io_desc;
 int ga_image_io(const ga_image_io_desc* d, void* stream);
 
@@ -450,7 +475,7 @@ typedef struct ga_interleave2_desc {
     int dact_prelu;           /* 1: act' = dact_x > 0 ? 1 : dact_scale[c] (nn.PReLU slopes in dact_scale, dact_shift ignored) */
     int lds;                  /* channel pitch of the source planes (0 = C): the four planes may be channel slices of ONE
                                  [N, H/2, W/2, 4C] tensor (StyleGAN2 up-sampling conv: one GEMM for all parities) */
-    int _reserved;
+    int dact_rep;             /* > 1: dact_x has N/dact_rep rows, output row n reads dact_x row n / dact_rep */
 } ga_interleave2_desc;
 int ga_interleave2(const ga_interleave2_desc* d, void* stream);
 

@@ -82,10 +82,14 @@ class Replay:
             if agree > best_agree:
                 best, best_agree = e, agree
         # a match may disagree on at most 0.1 % of the decisions (one, for small tensors); tensors with fewer than 48 decisions
-        # are never matched (a chance agreement would replay a stranger's decisions)
-        if own.numel() < 48 or best is None:
+        # are never matched by agreement (a chance agreement would replay a stranger's decisions)
+        ok = (best is not None and own.numel() >= 48 and
+              (1.0 - best_agree) * own.numel() <= max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5)
+        if not ok:
             best = None
             if x.shape[2:] == (1, 1):
+                # [N, F] tensors (squeeze-and-excite hidden units of any width): the other implementation hands them over in call
+                # order; a site takes the next one of its shape that disagrees on at most two decisions
                 for i in range(self.small_pos, min(self.small_pos + 4, len(self.small))):
                     e = self.small[i]
                     if tuple(e.shape) == tuple(x.shape[:2]) and int(((e > 0) != own[:, :, 0, 0]).sum()) <= 2:
@@ -94,9 +98,6 @@ class Replay:
             if best is None:
                 self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)))
                 return None
-        elif (1.0 - best_agree) * own.numel() > max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5:
-            self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)))
-            return None
         dec = best > 0
         diff = dec != own
         self.matched += 1
@@ -181,6 +182,10 @@ def _route(y_value: torch.Tensor, x: torch.Tensor, slope: torch.Tensor) -> torch
 
 def _replayed_slope(x, pos_slope, neg_slope, what):
     """values and gradient of a two-slope function under the replayed decisions (None: no match, caller falls back)"""
+    if not x.requires_grad:
+        # not on the differentiated path (e.g. the mapping network over the latent NOISE of a StyleGAN defender): no gradient is
+        # routed through this site, its decisions cannot move d loss / d input, and the other implementation need not keep it
+        return None
     xd = x.detach()
     dec = _STATE['replay'].sign(xd, what)
     if dec is None:
@@ -243,6 +248,8 @@ def max_pool2d(x: torch.Tensor, kernel_size: int, stride: int, padding: int = 0)
     k = kernel_size
     xp = F.pad(x, (padding,) * 4, value=float('-inf')) if padding else x
     cols = F.unfold(xp, k, stride=stride).view(n, c, k * k, -1)
+    if _STATE['replay'] is not None and not x.requires_grad:
+        return F.max_pool2d(x, kernel_size, stride, padding)          # off the differentiated path: see _replayed_slope
     if _STATE['replay'] is not None:
         idx = _STATE['replay'].argmax(cols.detach(), x.detach(), k, stride, padding)
         if idx is None:

@@ -373,3 +373,98 @@ def test_noise_ablation_with_injected_noise_matches_the_oracle(setup, tmp_path):
     m.model.fixed_noise(None, None)
     p = m.get_purified(x[:1].to(DEV))
     assert abs((p.cpu() - x[:1]).flatten(1).norm(dim=1).item() - 2.0) < 0.2
+
+
+def test_class_jacobian_k_cotangent_plan_equals_one_backward_per_class(setup, monkeypatch):
+    """SURVEY.md §8 row f1, the one-pass multi-class VJP: the per-class input gradients DeepFool / FAB need
+    (src/attacks/untargeted.py:526-560, :605-635: one `.backward(retain_graph=True)` per class) from the engine's K-cotangent
+    backward plan — ONE forward, ceil(columns / K) backward replays — against one autograd backward per class on the same
+    defender under the same noise.  With input noise configured (eps 2.0: clamp masks per replica, no shared encoder)."""
+    import math
+    from gen_adversarial_amd.attacks.l2_attacks import ClassJacobian
+    from gen_adversarial_amd.engine import Engine
+    args, model, ck, vsd, alphas = setup
+    spec = build_spec(CFG, RES)
+    B = 2
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(B, *RES, generator=g).to(DEV)
+    eps = [torch.randn(B * EOT, 4, gs.res, gs.res, generator=g).to(DEV) for gs in spec.groups]
+    noise = torch.randn(B * EOT, *RES, generator=g).to(DEV)
+    classes = torch.stack([torch.randperm(100, generator=g)[:5] for _ in range(B)]).to(DEV)
+    calls = {'n': 0}
+    real = Engine.backward
+
+    def counting(self, *a, **k):
+        calls['n'] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(Engine, 'backward', counting)
+    try:
+        for cols, n_cols in ((classes, 5), (None, 100)):
+            model.model.fixed_noise(eps, noise)
+            calls['n'] = 0
+            fast = ClassJacobian(model, x, cols)
+            assert fast._fast is not None, 'the HIP defender must offer its K-cotangent plan'
+            K = fast._fast.eng.cot_rep
+            assert K == min(n_cols, 512 // (B * EOT))
+            g_fast = fast.grads()
+            assert calls['n'] == math.ceil(n_cols / K), (calls['n'], n_cols, K)       # <= n_cols / K backward replays
+            monkeypatch.setattr(type(model.model), 'jacobian_cot_rows', 0)            # no K-cotangent plan: autograd per class
+            calls['n'] = 0
+            slow = ClassJacobian(model, x, cols)
+            assert slow._fast is None
+            g_slow = slow.grads()
+            assert calls['n'] == n_cols
+            monkeypatch.undo()
+            monkeypatch.setattr(Engine, 'backward', counting)
+            assert g_fast.shape == g_slow.shape == (B, n_cols, *RES)
+            e_l = (fast.logits - slow.logits).abs().max().item()
+            scale = g_slow.abs().amax(dim=(2, 3, 4), keepdim=True).clamp_min(1e-30)
+            e_g = ((g_fast - g_slow).abs() / scale).max().item()
+            print(f'   K-cotangent plan (K = {K}, {n_cols} columns): logits {e_l:.2e}, gradients {e_g:.2e} of each column\'s max')
+            assert e_l < 1e-5 and e_g < 1e-4
+    finally:
+        model.model.fixed_noise(None, None)
+
+
+@pytest.mark.parametrize('share', [False, True])
+def test_k_cotangent_engine_equals_repeated_backward(setup, share):
+    """Engine(cot_rep = K) against K backward replays of the plain engine, without input noise: share = True runs the encoder once
+    per image (its cotangents then meet in ga_rep_sum with K folded into the row), share = False the literal repeat; dense random
+    cotangents (not only one-hot class seeds), gradient from the logits and from the purified image."""
+    from gen_adversarial_amd.engine import Engine, WeightStore
+    _, _, ck, vsd, alphas = setup
+    spec = build_spec(CFG, RES)
+    sd = ck['state_dict_temp=0.6']
+    vspec = build_vgg_spec(100, 16)
+    rows, rep, K = 8, 4, 3
+    store = WeightStore(DEV)
+    g = torch.Generator().manual_seed(23)
+    imgs = torch.rand(rows // rep, *RES, generator=g).to(DEV)
+    eps = [torch.randn(rows, 4, gs.res, gs.res, generator=g).to(DEV) for gs in spec.groups]
+    cot = torch.randn(rows, K, 100, generator=g).to(DEV)
+    cot_img = torch.randn(rows, K, *RES, generator=g).to(DEV)
+    engs = {k: Engine(sd, CFG, RES, vsd, vspec, rows=rows, rep=rep, alphas=alphas, device=DEV, store=store, share_encoder=share,
+                      cot_rep=k) for k in (1, K)}
+    for e in engs.values():
+        e.x_in.copy_(imgs)
+        for dst, src in zip(e.eps, eps):
+            dst.copy_(src)
+        e.forward()
+    assert torch.equal(engs[1].logits, engs[K].logits)
+    engs[K].dlogits.view(rows, K, 100).copy_(cot)
+    engs[K].backward()
+    got = engs[K].dx.view(rows // rep, K, *RES).clone()
+    engs[K].dpurified.view(rows, K, *RES).copy_(cot_img)
+    engs[K].backward(from_logits=False, from_purified=True)
+    got_img = engs[K].dx.view(rows // rep, K, *RES).clone()
+    for k in range(K):
+        engs[1].dlogits.view(rows, 100).copy_(cot[:, k])
+        engs[1].backward()
+        ref = engs[1].dx.clone()
+        e = (got[:, k] - ref).abs().max().item() / ref.abs().max().item()
+        engs[1].dpurified.copy_(cot_img[:, k])
+        engs[1].backward(from_logits=False, from_purified=True)
+        ref_img = engs[1].dx.clone()
+        e_img = (got_img[:, k] - ref_img).abs().max().item() / ref_img.abs().max().item()
+        print(f'   cotangent {k}: from logits {e:.2e}, from the purified image {e_img:.2e} (relative to max |g|)')
+        assert e < 1e-5 and e_img < 1e-5

@@ -152,3 +152,44 @@ def test_class_gradients_one_pass_per_class_for_the_whole_batch():
             np.testing.assert_allclose(g[b, j].numpy(), ref[0].numpy(), atol=1e-6)
     y2, g2 = class_gradients(net, x)
     assert g2.shape == (3, 6, 3, 16, 16) and torch.allclose(g2[1, 5], g[1, 0], atol=1e-6)
+
+
+def test_class_jacobian_asks_the_defender_first_and_deepfool_pays_for_gradients_only_while_active(gold):
+    """ClassJacobian protocol: a net that offers `class_jacobian(x, classes)` (the HIP defender's K-cotangent
+    plan) is asked instead of one autograd backward per class; DeepFool reads the logits first and requests the K gradients only
+    while some image is still active (the terminating iteration is a forward alone)."""
+    from gen_adversarial_amd.attacks.l2_attacks import ClassJacobian
+    net = toy_net()
+    stats = {'forwards': 0, 'grads': 0}
+
+    class Offer:
+        def __init__(self, x, classes):
+            stats['forwards'] += 1
+            self.inner = None
+            self.x, self.classes = x, classes
+            with torch.no_grad():
+                self.logits = net(x)
+
+        def grads(self):
+            stats['grads'] += 1
+            net.class_jacobian = None          # the inner ClassJacobian must take the autograd path
+            try:
+                return ClassJacobian(net, self.x, self.classes).grads()
+            finally:
+                net.class_jacobian = offer
+
+    def offer(x, classes=None):
+        return Offer(x, classes)
+    net.class_jacobian = offer
+    try:
+        images, labels = torch.from_numpy(gold['images']), torch.from_numpy(gold['labels'])
+        s, b, a = DeepFool(num_classes=4, overshoot=0.02, max_iter=10)(images.clone(), labels.clone(), net)
+        # the results are those of the plain path (the goldens of the reference's own DeepFool cover that one)
+        del net.class_jacobian
+        s0, b0, a0 = DeepFool(num_classes=4, overshoot=0.02, max_iter=10)(images.clone(), labels.clone(), net)
+        assert torch.equal(torch.as_tensor(s), torch.as_tensor(s0)) and torch.allclose(torch.as_tensor(b), torch.as_tensor(b0))
+        np.testing.assert_allclose(a.numpy(), a0.numpy(), atol=1e-6)
+        assert stats['forwards'] >= 2 and stats['grads'] == stats['forwards'] - 1, stats     # the last iteration asked for no gradient
+    finally:
+        if hasattr(net, 'class_jacobian'):
+            del net.class_jacobian
