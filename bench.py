@@ -129,6 +129,37 @@ def measure_pmc_traffic(args):
                         f'{nf} conv launches; bytes = 2 x FETCH_SIZE KB (gfx950 counts half of wide coalesced reads) + WRITE_SIZE KB')
 
 
+def measured_peaks(device):
+    """The two peaks the roofline figures are normalised by, MEASURED on this box with the library's
+    microbenchmarks (csrc/microbench.hip), HIP events on the current stream: a 16-B-per-lane copy of 1 GiB (read + write bytes)
+    and a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands (2 workgroups of 4 waves per CU)."""
+    from gen_adversarial_amd import _lib as L
+    st = torch.cuda.current_stream(device).cuda_stream
+    n = 256 * 1024 * 1024
+    src = torch.empty(n, device=device).normal_()
+    dst = torch.empty_like(src)
+    blocks, iters = 512, 20000
+    out = torch.empty(blocks * 256, device=device)
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / 1e3 / reps
+    t_copy = timed(lambda: L.check(L.lib.ga_microbench_hbm_copy(src.data_ptr(), dst.data_ptr(), n, st), 'hbm_copy'), 10)
+    t_mfma = timed(lambda: L.check(L.lib.ga_microbench_mfma_bf16(out.data_ptr(), blocks, iters, st), 'mfma_bf16'), 5)
+    flops = blocks * 4 * iters * 8 * 2 * 32 * 32 * 16
+    del src, dst, out
+    return {'hbm_copy_tbps': 2 * 4 * n / t_copy / 1e12, 'bf16_mfma_tflops': flops / t_mfma / 1e12,
+            'how': 'ga_microbench_hbm_copy (1 GiB float4 copy, read + write bytes / time) and ga_microbench_mfma_bf16 (bare '
+                   '32x32x16 bf16 MFMA loop, pseudo-random operands, 512 workgroups x 4 waves x 160000 MFMAs), HIP events, this box'}
+
+
 def build_model(device, rows, rep, seed=0, precision='bf16x3', share_encoder=False, store=None):
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, init_nvae_state_dict
@@ -149,8 +180,9 @@ class AttackStep:
     """PGD-Linf iteration (eps 8/255, step 2/255) on `images`, processed as chunks of eng.rows // rep images that
     alternate over the engines (one HIP stream each; engines share the folded weights)."""
 
-    def __init__(self, engines, streams, labels, x_orig, eps=8.0 / 255.0, step=2.0 / 255.0):
+    def __init__(self, engines, streams, labels, x_orig, eps=8.0 / 255.0, step=2.0 / 255.0, bpda=False):
         self.engines, self.streams = engines, streams
+        self.bpda = bpda          # BPDA (the attack BASELINE.json configs[3] names): backward through the classifier only
         self.labels, self.x_orig, self.eps, self.step_size = labels, x_orig, eps, step
         self.x_adv = x_orig.clone()
         self.rep = engines[0].rep
@@ -167,7 +199,7 @@ class AttackStep:
         p = torch.softmax(logits, dim=1)
         p[torch.arange(p.shape[0], device=p.device), self.labels[lo:hi]] -= 1.0           # d CE / d mean-logits
         eng.dlogits.view(-1, self.rep, p.shape[-1]).copy_((p / self.rep).unsqueeze(1).expand(-1, self.rep, -1))
-        eng.backward()
+        eng.backward(identity_purifier=True) if self.bpda else eng.backward()
         nxt = self.x_adv[lo:hi] + self.step_size * eng.dx.sign()
         xo = self.x_orig[lo:hi]
         self.x_adv[lo:hi] = torch.min(torch.max(nxt, xo - self.eps), xo + self.eps).clamp_(0.0, 1.0)
@@ -590,6 +622,8 @@ def main():
     ap.add_argument('--pmc-child', action='store_true', help='internal: the process the PMC passes profile (see measure_pmc_traffic)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc passes (roofline.traffic = null)')
     ap.add_argument('--pmc-timeout', type=int, default=240)
+    ap.add_argument('--robust-acc-images', type=int, default=512,
+                    help='images of the robust-accuracy delta measurement beside the cpu baseline (0: skip; multiples of 128)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip every secondary measurement (rows256, shared encoder, fp32, reference protocol, e4e defender)')
     ap.add_argument('--stub-engine', action='store_true',
@@ -712,6 +746,11 @@ def main():
         conv_s = (fc_ms + bc_ms) / 1e3
         achieved = flops / conv_s / 1e12
         peak = PEAK_BF16X3_TFLOPS if args.precision == 'bf16x3' else PEAK_FP32_MFMA_TFLOPS
+        try:
+            mp = measured_peaks(device)
+        except Exception as ex:
+            mp = {'hbm_copy_tbps': None, 'bf16_mfma_tflops': None, 'how': f'failed: {ex}'}
+        meas_ceiling = mp['bf16_mfma_tflops'] / 3.0 if (mp['bf16_mfma_tflops'] and args.precision == 'bf16x3') else None
         out = {
             'metric': 'purified images/sec (attack+encode+decode)',
             'value': rows_total / dt,
@@ -732,6 +771,8 @@ def main():
             'roofline': {'bound': 'mfma',
                          'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_bytes,
+                         'measured_peak': dict(mp, bf16x3_ceiling_tflops=meas_ceiling),
+                         'frac_of_measured_peak': (achieved / meas_ceiling) if meas_ceiling else None,
                          'traffic_note': 'HBM bytes per conv launch: ' + pmc_note + '; algorithmic bytes per launch beside it',
                          'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                          'peak_note': ('dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per fp32-class product; achieved counts '
@@ -762,6 +803,19 @@ def main():
                 'bound': 'vector ALU + LDS of one wave per SIMD (two quarter-rate transcendentals per SiLU, 25 FMAs and 2.7 LDS reads per '
                          'depthwise output); the contractions are 25 % of its clocks (tools/dec_cell_trace.py)',
                 'share_of_plan_ms': cell_ms / (f_ms + b_ms)}
+        if world == 1 and not args.no_secondary and not args.stub_engine:
+            # BASELINE.json configs[3] names "PGD-40 + BPDA": the same 8192-row step with the purifier's Jacobian replaced by the
+            # identity in the backward pass (forward through purifier + classifier, backward through the classifier alone)
+            try:
+                st_b = AttackStep(engines, streams, labels, x, bpda=True)
+                tb = _time_steps(st_b, 3, warm=1)
+                out.setdefault('secondary', {})['pgd_bpda'] = {
+                    'rows_per_s': rows_per_step / tb, 'ms_per_step': tb * 1e3,
+                    'what': f'--attack pgd-bpda at the headline configuration: {args.images} images x EoT {args.eot} per step, full forward, '
+                            'backward through the VGG classifier only (Engine.backward(identity_purifier=True))'}
+                del st_b
+            except Exception as ex:
+                out.setdefault('secondary', {})['pgd_bpda'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
         if world == 1 and rows_per_step != 256 and not args.no_rows256:
             # SURVEY.md §8(d) words configs[1] as R = 256 defender rows (8 images x EoT 32) in ONE plan run: the same
             # attack step at that size, one engine, one stream, reported beside the headline (never as `value`)
@@ -857,6 +911,19 @@ def main():
                                 'on (the kernels the timed 512-row plans select); tolerance of the path: 1e-3 on logits'}
                 out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)
                 log('cpu baseline done')
+                if args.robust_acc_images > 0:
+                    # robust-accuracy delta HIP vs oracle at a sample size that resolves 0.2 % (the oracle as the checker, on a
+                    # reduced model it can run hundreds of images x PGD steps of: tests/robust_acc.py)
+                    log(f'robust-accuracy delta on {args.robust_acc_images} images (oracle on the host cores) ...')
+                    try:
+                        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+                        from robust_acc import robust_accuracy_delta
+                        free_gpu_memory()
+                        out['robust_accuracy_delta'] = robust_accuracy_delta(device, n_images=args.robust_acc_images, eot=4, steps=6,
+                                                                             precision=args.precision)
+                    except Exception as ex:
+                        out['robust_accuracy_delta'] = {'delta': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
+                    log('robust-accuracy delta done')
             except Exception as ex:   # the baseline is a reported number, never a reason to lose the bench line
                 out['cpu_baseline'] = {'value': None, 'unit': 'rows/s', 'cores': 0, 'kind': 'port', 'sample': f'failed: {ex}'}
         print(json.dumps(out))

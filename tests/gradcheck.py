@@ -52,6 +52,9 @@ def assert_grad_given_engine_decisions(eng, loss_fn, x, got, tol=1e-3, what='inp
     reproduces the golden are compared against the reference's numbers; the others are reported and covered by the
     oracle-replay comparison alone."""
     small = [t.detach() for t in getattr(eng, 'small_kinks', [])]                    # SE hidden pre-activations, in call order
+    # an encoder shared by the EoT replicas keeps one row per IMAGE: the oracle's literal repeat sees it once per replica
+    small = [t.repeat_interleave(eng.rows // t.shape[0], dim=0) if (t.shape[0] != eng.rows and eng.rows % t.shape[0] == 0) else t
+             for t in small]
     small = [(t[rows] if rows is not None and t.shape[0] == eng.rows else t).float().cpu() for t in small]
     with K.replaying(engine_candidates(eng, rows), small=small) as rp:
         xr = x.detach().clone().requires_grad_(True)
