@@ -77,7 +77,7 @@ class SamplerDesc(C.Structure):
                 ('z', fp), ('dz', fp), ('dmu_q', fp), ('dp', fp),
                 ('N', i32), ('h', i32), ('w', i32), ('NL', i32),
                 ('alpha', f32), ('one_minus_alpha', f32), ('temp', f32), ('backward', i32),
-                ('q_rep', i32), ('dmu_q_rows', fp), ('ldz', i32), ('act_rep', i32)]
+                ('q_rep', i32), ('dmu_q_rows', fp), ('ldz', i32), ('act_rep', i32), ('mode', i32), ('_reserved', i32)]
 
 
 class DmlDesc(C.Structure):

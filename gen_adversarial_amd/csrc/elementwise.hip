@@ -324,6 +324,23 @@ __global__ void __launch_bounds__(256) sampler_kernel(const ga_sampler_desc d, c
         // backward with K cotangents per forward row (act_rep = K): p, eps and mu_q are the forward's tensors, row n / K
         const int na = (d.backward && d.act_rep > 1) ? n / d.act_rep : n;
         const long apix = (long)na * hw + p;
+        if (d.mode == 1) {      // ND-VAE posterior sample: both distributions' parameters enter as sums (NVAE.py:608-634)
+            const float e1 = d.eps_nchw ? d.eps[((size_t)na * d.NL + c) * hw + p] : d.eps[apix * d.NL + c];
+            const float mu_s = d.mu_q[apix * d.ldq + c] + d.p[apix * d.ldp + c];
+            const float ls_s = d.mu_q[apix * d.ldq + d.NL + c] + d.p[apix * d.ldp + d.NL + c];
+            const float ex = expf(softclamp5(ls_s));
+            if (!d.backward) {
+                d.z[zi] = softclamp5(mu_s) + (ex + 0.01f) * e1;
+            } else {
+                const float dz = d.dz[zi];
+                const float dmu = dz * dsoftclamp5(mu_s), dls = dz * e1 * ex * dsoftclamp5(ls_s);
+                d.dmu_q[pix * d.ldq + c] = dmu;
+                d.dmu_q[pix * d.ldq + d.NL + c] = dls;
+                d.dp[pix * d.ldp + c] = dmu;
+                d.dp[pix * d.ldp + d.NL + c] = dls;
+            }
+            continue;
+        }
         const long qpix = d.q_rep > 1 ? (long)(na / d.q_rep) * hw + p : apix;
         const float mq = d.mu_q[qpix * d.ldq + c];
         const float mp = d.p ? d.p[apix * d.ldp + c] : 0.f;
@@ -1221,6 +1238,8 @@ extern "C" int ga_sampler_mix(const ga_sampler_desc* d, void* s) {
     if (d->backward && (!d->dz || (d->q_rep > 1 ? !d->dmu_q_rows : !d->dmu_q) || (d->p && !d->dp))) return GA_E_BADARG;
     if (d->q_rep > 1 && d->N % d->q_rep) return GA_E_BADARG;
     if (d->act_rep > 1 && (!d->backward || d->N % d->act_rep || (d->q_rep > 1 && (d->N / d->act_rep) % d->q_rep))) return GA_E_BADARG;
+    if (d->mode == 1 && (!d->p || d->ldq < 2 * d->NL || d->q_rep > 1 || (d->backward && (!d->dmu_q || !d->dp)))) return GA_E_BADARG;
+    if (d->mode != 0 && d->mode != 1) return GA_E_UNSUPPORTED;
     const long total = (long)d->N * d->h * d->w * d->NL;
     hipLaunchKernelGGL(sampler_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, *d, total);
     return check_launch();

@@ -202,6 +202,13 @@ typedef struct ga_sampler_desc {
     int act_rep;       /* backward, > 1: K cotangents per forward row.  N counts cotangent rows (dz, dp, dmu_q / dmu_q_rows); p and eps
                           are the forward's [N/act_rep, ...] tensors read at row n / act_rep, mu_q at row (n / act_rep) / q_rep.  dmu_q
                           is then written per cotangent row only through dmu_q_rows when q_rep > 1 (as without act_rep) */
+    int mode;          /* 0: the interpolation above.  1: the posterior sample of the ND-VAE competitor's Sampler
+                          (src/defenses/competitors/nd_vae/modules/models/NVAE.py:608-634, Normal :88-101): mu_q is [N,h,w,ldq] =
+                          (mu_q | logsig_q), p is [N,h,w,ldp] = (mu_p | logsig_p), ldq, ldp >= 2 NL,
+                            z = 5 tanh((mu_q + mu_p)/5) + (exp(5 tanh((logsig_q + logsig_p)/5)) + 0.01) * eps;
+                          backward writes dmu_q [N,h,w,ldq] and dp [N,h,w,ldp], channels [0, 2 NL) (the two are equal: the
+                          parameters enter as sums).  alpha, temp, q_rep unused. */
+    int _reserved;
 } ga_sampler_desc;
 int ga_sampler_mix(const ga_sampler_desc* d, void* stream);
 

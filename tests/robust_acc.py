@@ -17,7 +17,7 @@ import time
 
 import torch
 
-CFG = {'initial_channels': 4, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 1, 'num_scales': 2,
+CFG = {'initial_channels': 4, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 2, 'num_scales': 2,
        'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
        'num_latent_per_group': 4, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
 RES = (3, 64, 64)
@@ -50,13 +50,15 @@ def robust_accuracy_delta(device='cuda:0', n_images=512, eot=4, steps=6, eps=8.0
     t_cpu = t_gpu = 0.0
     keep = {'hip': [], 'cpu': [], 'clean_agree': []}
 
+    dummy_noise = torch.ones(rows, *RES)          # scaled by eps = 0 (abstract_models.py:132-138 divides by its norm: must not be 0)
+
     def draw():
         return [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=g) for gs in spec.groups]
 
     def cpu_logits(x, e, grad):
         xr = x.clone().requires_grad_(grad)
         with torch.set_grad_enabled(grad):
-            lg, _ = D.nvae_defender(sd, spec, vsd, vspec, xr.repeat_interleave(eot, dim=0), alphas, e, torch.zeros(rows, *RES), 0.0)
+            lg, _ = D.nvae_defender(sd, spec, vsd, vspec, xr.repeat_interleave(eot, dim=0), alphas, e, dummy_noise, 0.0)
             mean = lg.view(-1, eot, lg.shape[-1]).mean(dim=1)
         return xr, mean
 

@@ -403,3 +403,25 @@ def test_trans_defender_oracle_matches_reference_purify():
     ref = torch.from_numpy(g['purify.gx'])
     rel = ((gx - ref).double().norm() / ref.double().norm()).item()
     assert rel < 5e-3, rel
+
+
+@pytest.mark.parametrize('case', ['A', 'B'])
+def test_ndvae_oracle_matches_the_reference_golden(case):
+    """the ND-VAE competitor purifier (Defence_NVAE + NDVaeDefenseModel.purify) restated in
+    oracle/ndvae_oracle.py against the reference's own modules (tests/golden/make_ndvae_golden.py)."""
+    from gen_adversarial_amd.ndvae_spec import build_ndvae_spec, init_ndvae_state_dict
+    from oracle import ndvae_oracle as N
+    g = load_golden('ndvae.npz')
+    cfg = {str(k): int(v) for k, v in zip(g[f'{case}.cfg_keys'], g[f'{case}.cfg_vals'])}
+    spec = build_ndvae_spec(cfg)
+    sd = init_ndvae_state_dict(cfg, int(g[f'{case}.seed']))
+    t = lambda k: torch.from_numpy(g[f'{case}.{k}'])                                     # noqa: E731
+    eps = [t(f'eps{i}') for i in range(len(spec.latent_shapes))]
+    assert [tuple(e.shape[1:3]) for e in eps] == [(c, r) for c, r in spec.latent_shapes]
+    logits = N.ndvae_logits(sd, spec, t('x'), eps, t('h'))
+    assert (logits - t('logits_clean')).abs().max().item() < 1e-4 * max(1.0, t('logits_clean').abs().max().item())
+    x = t('x').clone().requires_grad_(True)
+    pur = N.ndvae_purify(sd, spec, x, t('noise'), float(g[f'{case}.noise_std']), eps, t('h'))
+    assert (pur - t('purified')).abs().max().item() < 1e-5
+    (gx,) = torch.autograd.grad((pur * t('cot')).sum(), [x])
+    assert (gx - t('gx')).abs().max().item() < 1e-5 * max(1.0, t('gx').abs().max().item())
