@@ -158,7 +158,10 @@ class _EngineOwner:
                 eng.noise.copy_(inp)
             else:
                 eng.noise.normal_()
-            eng.noise_coef.copy_(eng.noise_eps / eng.noise.flatten(1).norm(dim=1))
+            if getattr(eng, 'noise_is_std', False):          # competitors: x + randn * std (nd_vae/purification_model.py:21)
+                eng.noise_coef.fill_(eng.noise_eps)
+            else:
+                eng.noise_coef.copy_(eng.noise_eps / eng.noise.flatten(1).norm(dim=1))
 
     @staticmethod
     def _snapshot_noise(eng: Engine):

@@ -9,14 +9,19 @@ import torch
 from . import _lib as L
 from . import folding as F
 from .engine_core import IMG_LD, RES_SCALE, Act, _ptr
+from .ndvae_spec import NdGenCell, NdResCell
 from .nvae_spec import DecCellSpec, EncCellSpec
 
 
 class NvaeBuilder:
     # ------------------------------------------------------------------------------------------------ cells
     def enc_cell(self, cell: EncCellSpec, x: Act) -> Act:
-        """ResidualCellEncoder (architecture.py:96-136): fwd ops now, bwd ops registered for later."""
-        wts = self.devd(cell.prefix, lambda: F.fold_enc_cell(self.nvae_sd, cell))
+        """ResidualCellEncoder (architecture.py:96-136): fwd ops now, bwd ops registered for later.  Also the ND-VAE competitor's
+        Residual_Cell_NVAE (competitors/nd_vae/modules/models/NVAE.py:255-297: the same chain with an unscaled residual and a
+        2x2 / stride-2 skip = FactorizedReduce), told apart by the cell spec."""
+        nd = isinstance(cell, NdResCell)
+        wts = self.devd(('nd.' if nd else '') + cell.prefix, lambda: (F.fold_nd_res_cell if nd else F.fold_enc_cell)(self.nvae_sd, cell))
+        rs = getattr(cell, 'res_scale', RES_SCALE)
         n, h, w = x.n, x.h, x.w
         st = 2 if cell.down else 1
         ho, wo = h // st, w // st
@@ -29,21 +34,22 @@ class NvaeBuilder:
         self.conv(self.fwd, p + '.conv2', t1.t, wts['w2'], t2.t, bias=wts['b2'], K=3, pad=1, pro_act=L.GA_ACT_SILU)
         if cell.down:
             sk = Act(self, n, ho, wo, cell.cout, p + '.skip')
-            self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sk.t, bias=wts['bs'], K=1, sn=2, pad=0, pro_act=L.GA_ACT_SILU)
+            ks = 2 if wts['ws'].shape[1] == 4 * x.c else 1          # SkipDown: 1x1 / 2; FactorizedReduce: 2x2 / 2 (one tap per quarter)
+            self.conv(self.fwd, p + '.skip', x.t, wts['ws'], sk.t, bias=wts['bs'], K=ks, sn=2, pad=0, pro_act=L.GA_ACT_SILU)
             skip_t = sk.t
         else:
             skip_t = x.t
         if self.se_merges(t2, ho * wo):
-            gate, hid = self.se_forward(p, t2, wts, ho * wo, merge=(skip_t, out.t))
+            gate, hid = self.se_forward(p, t2, wts, ho * wo, res_scale=rs, merge=(skip_t, out.t))
         else:
-            gate, hid = self.se_forward(p, t2, wts, ho * wo)
+            gate, hid = self.se_forward(p, t2, wts, ho * wo, res_scale=rs)
             a = L.SeApplyDesc()
             a.skip, a.t, a.gate, a.out = _ptr(skip_t), _ptr(t2.t), _ptr(gate), _ptr(out.t)
-            a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = n, ho, wo, cell.cout, 0, RES_SCALE
+            a.N, a.H, a.W, a.C, a.skip_mode, a.res_scale = n, ho, wo, cell.cout, 0, rs
             self.fwd.add(a, p + '.merge')
 
         def backward():
-            ps, pb = self.se_backward(p, out.g, t2, wts, gate, hid, ho * wo)
+            ps, pb = self.se_backward(p, out.g, t2, wts, gate, hid, ho * wo, res_scale=rs)
             dt1 = self.scratch((out.g.shape[0], ho, wo, cell.cout), 'enc_dt1')
             self.conv(self.bwd, p + '.conv2^T', out.g, wts['w2_bwd'], dt1, K=3, pad=1,
                       pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t1.t, dact_act=L.GA_ACT_SILU)
@@ -59,15 +65,19 @@ class NvaeBuilder:
 
     def dec_cell(self, cell: DecCellSpec, x: Act) -> Act:
         """ResidualCellDecoder (architecture.py:139-186) with nearest-up folded into the depthwise read and the
-        SkipUp 1x1 applied before its bilinear interpolation."""
-        wts = self.devd(cell.prefix, lambda: F.fold_dec_cell(self.nvae_sd, cell))
+        SkipUp 1x1 applied before its bilinear interpolation.  Also the ND-VAE competitor's Generative_Cell_NVAE
+        (competitors/nd_vae/modules/models/NVAE.py:156-228): the same chain with one more 1x1 conv between the depthwise conv and
+        its BatchNorm (`wp`) and an unscaled residual."""
+        nd = isinstance(cell, NdGenCell)
+        wts = self.devd(('nd.' if nd else '') + cell.prefix, lambda: (F.fold_nd_gen_cell if nd else F.fold_dec_cell)(self.nvae_sd, cell))
+        rs = getattr(cell, 'res_scale', RES_SCALE)
         n, h, w = x.n, x.h, x.w
         up = cell.up
         H, W = (2 * h, 2 * w) if up else (h, w)
         hid_c = cell.hidden
         p = cell.prefix
         # whole-image tiles at 128 / 256 channels: ONE launch per direction, the two hid_c-wide tensors never reach HBM
-        fused = (not up and self.precision == 'bf16x3' and self.fuse_dec_cells and cell.cout == x.c
+        fused = (not up and not nd and self.precision == 'bf16x3' and self.fuse_dec_cells and cell.cout == x.c
                  and L.lib.ga_dec_cell_supported(n, H, W, x.c, hid_c) == 1
                  and n * H * W // (256 if x.c == 128 else 128) >= self.fuse_min_workgroups)
         t3 = Act(self, n, H, W, cell.cout, p + '.t3')
@@ -95,9 +105,13 @@ class NvaeBuilder:
             d.x, d.w, d.bias, d.y = _ptr(t1.t), _ptr(wts['wd']), _ptr(wts['bd']), _ptr(t2.t)
             d.N, d.H, d.W, d.C, d.pro_act, d.up2 = n, H, W, hid_c, L.GA_ACT_SILU, int(up)
             self.fwd.add(d, p + '.dw5')
+            if nd:          # depthwise_separable_conv: depthwise (above, bias only) then pointwise with the BatchNorm behind it folded in
+                u = t2
+                t2 = Act(self, n, H, W, hid_c, p + '.t2p')
+                self.conv(self.fwd, p + '.pw', u.t, wts['wp'], t2.t, bias=wts['bp'], K=1)
             self.conv(self.fwd, p + '.pw2', t2.t, wts['w2'], t3.t, bias=wts['b2'], K=1, pro_act=L.GA_ACT_SILU)
         if not up and self.se_merges(t3, H * W):
-            gate, hid = self.se_forward(p, t3, wts, H * W, merge=(x.t, out.t))
+            gate, hid = self.se_forward(p, t3, wts, H * W, res_scale=rs, merge=(x.t, out.t))
         else:
             a = L.SeApplyDesc()
             if up:
@@ -106,14 +120,14 @@ class NvaeBuilder:
                 a.skip, a.skip_mode = _ptr(sl.t), 1
             else:
                 a.skip, a.skip_mode = _ptr(x.t), 0
-            gate, hid = self.se_forward(p, t3, wts, H * W)
+            gate, hid = self.se_forward(p, t3, wts, H * W, res_scale=rs)
             a.t, a.gate, a.out = _ptr(t3.t), _ptr(gate), _ptr(out.t)
-            a.N, a.H, a.W, a.C, a.res_scale = n, H, W, cell.cout, RES_SCALE
+            a.N, a.H, a.W, a.C, a.res_scale = n, H, W, cell.cout, rs
             self.fwd.add(a, p + '.merge')
 
         def backward():
             nc = out.g.shape[0]                                 # cotangent rows: n * cot_rep
-            ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W)
+            ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W, res_scale=rs)
             dt1 = self.scratch((nc, h, w, hid_c), 'dec_dt1')
             if fused:
                 b = fused_desc(1)
@@ -124,6 +138,10 @@ class NvaeBuilder:
                 dt2 = self.scratch((nc, H, W, hid_c), 'dec_dt2')
                 self.conv(self.bwd, p + '.pw2^T', out.g, wts['w2_bwd'], dt2, K=1,
                           pro_scale=ps, pro_shift=pb, pro_per_row=1, dact_x=t2.t, dact_act=L.GA_ACT_SILU)
+                if nd:      # the pointwise conv's transpose (linear: no act' between it and the depthwise conv)
+                    du = self.scratch((nc, H, W, hid_c), 'dec_du')
+                    self.conv(self.bwd, p + '.pw^T', dt2, wts['wp_bwd'], du, K=1)
+                    dt2 = du
                 b = L.DwDesc()
                 b.x, b.w, b.dact_x, b.y = _ptr(dt2), _ptr(wts['wd_bwd']), _ptr(t1.t), _ptr(dt1)
                 b.N, b.H, b.W, b.C, b.dact_act, b.pool2, b.act_rep = nc, H, W, hid_c, L.GA_ACT_SILU, int(up), self.cot_rep

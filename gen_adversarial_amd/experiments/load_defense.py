@@ -17,6 +17,7 @@ import yaml
 from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
 from ..defenses.ablations.models import GaussianBlurDefenseModel, GaussianNoiseDefenseModel
+from ..defenses.competitors.nd_vae import NDVaeDefenseModel, load_NDVAE
 from ..defenses.ours.models import (CarsTypeClassifier, CelebaGenderClassifier, CelebaIdentityClassifier,
                                    E4EStyleGanDefenseModel, NVAEDefenseModel, TransStyleGanDefenseModel)
 from ..defenses.wrappers import EoTWrapper
@@ -73,6 +74,13 @@ def load(args: Namespace):
             defense_model = GaussianNoiseDefenseModel(base_classifier, 2. if args.experiment == 'ids' else 4.)
         else:
             defense_model = GaussianBlurDefenseModel(base_classifier)
+        defense_model = EoTWrapper(defense_model, args.eot_steps)
+        defense_model.get_purified = lambda x: defense_model.model.purify(x)
+    elif args.defense_type == 'ND-VAE':
+        # load_defense.py:108-124: Defence_NVAE(x_channels, encoding_channels, pre_proc_groups, scales, groups, cells, image_size)
+        nd_vae = load_NDVAE(d_params.autoencoder_path, d_params.x_channels, d_params.encoding_channels, d_params.pre_proc_groups,
+                            d_params.scales, d_params.groups, d_params.cells, args.image_size)
+        defense_model = NDVaeDefenseModel(base_classifier, nd_vae, d_params.noise_std)
         defense_model = EoTWrapper(defense_model, args.eot_steps)
         defense_model.get_purified = lambda x: defense_model.model.purify(x)
     elif args.defense_type == 'ours':

@@ -110,6 +110,77 @@ def fold_enc_cell(sd: SD, cell) -> dict:
     return out
 
 
+def _nd_se(sd: SD, prefix: str) -> dict:
+    """SE_Block of the ND-VAE competitor (NVAE.py:57-69): nn.Sequential(Linear, ReLU, Linear, Sigmoid) under `.se`"""
+    return {'se_w1': f32(sd[f'{prefix}.se.0.weight']), 'se_b1': f32(sd[f'{prefix}.se.0.bias']),
+            'se_w2': f32(sd[f'{prefix}.se.2.weight']), 'se_b2': f32(sd[f'{prefix}.se.2.bias'])}
+
+
+def fold_nd_res_cell(sd: SD, cell) -> dict:
+    """Residual_Cell_NVAE (competitors/nd_vae/modules/models/NVAE.py:255-297) in the layout of fold_enc_cell: bn1 = the prologue
+    affine of conv1, bn2 folded into conv1; FactorizedReduce (:117-135) = ONE 2x2 / stride-2 / pad-0 convolution whose four
+    output-channel quarters each see one tap: conv_1 pixel (0,0), conv_2 (1,1), conv_3 (0,1), conv_4 (1,0) of every 2x2 block."""
+    p = cell.prefix
+    s0, t0 = bn_affine64(sd, f'{p}.bn1')
+    w1 = sd[f'{p}.conv1.weight'].double()
+    s1, t1 = bn_affine64(sd, f'{p}.bn2')
+    w1f = w1 * s1.view(-1, 1, 1, 1)
+    b1f = sd[f'{p}.conv1.bias'].double() * s1 + t1
+    w2 = sd[f'{p}.conv2.weight'].double()
+    out = {'pro_scale': f32(s0), 'pro_shift': f32(t0),
+           'w1': f32(conv_fwd_layout(w1f)), 'w1_bwd': f32(conv_bwd_layout(w1f)), 'b1': f32(b1f),
+           'w2': f32(conv_fwd_layout(w2)), 'w2_bwd': f32(conv_bwd_layout(w2)), 'b2': f32(sd[f'{p}.conv2.bias'].double())}
+    out.update(_nd_se(sd, f'{p}.squeeze_excitation'))
+    if cell.down:
+        ws = torch.zeros(cell.cout, cell.cin, 2, 2, dtype=torch.float64)
+        bs, o = [], 0
+        for i, (kh, kw) in enumerate(((0, 0), (1, 1), (0, 1), (1, 0)), start=1):
+            wi = sd[f'{p}.skip.conv_{i}.weight'].double()[:, :, 0, 0]
+            ws[o:o + wi.shape[0], :, kh, kw] = wi
+            bs.append(sd[f'{p}.skip.conv_{i}.bias'].double())
+            o += wi.shape[0]
+        assert o == cell.cout
+        out['ws'] = f32(conv_fwd_layout(ws))
+        out['bs'] = f32(torch.cat(bs))
+        for key, wsrc in (('w1_sub', w1f), ('ws_sub', ws)):                  # sub-pixel kernels of the two stride-2 transposes
+            for (a, b), (wm, kh, kw) in subpixel_weights(wsrc).items():
+                out[f'{key}{a}{b}'] = wm
+    return out
+
+
+def fold_nd_gen_cell(sd: SD, cell) -> dict:
+    """Generative_Cell_NVAE (NVAE.py:156-228) in the layout of fold_dec_cell plus the pointwise conv of its
+    depthwise_separable_conv (`wp`): bn1 and bn_expanded1 folded into `expand`, the depthwise conv keeps its own bias,
+    bn_expanded2 folded into the pointwise conv, bn2 into `expand2`; the up-sampling cell's skip is bilinear x2 then a 1x1 conv
+    (the two commute: the engine convolves at low resolution)."""
+    p = cell.prefix
+    s0, t0 = bn_affine64(sd, f'{p}.bn1')
+    w1 = sd[f'{p}.expand.weight'].double()[:, :, 0, 0]
+    s1, t1 = bn_affine64(sd, f'{p}.bn_expanded1')
+    w1f = s1.view(-1, 1) * w1 * s0.view(1, -1)
+    b1f = s1 * (w1 @ t0 + sd[f'{p}.expand.bias'].double()) + t1
+    wd = sd[f'{p}.dep_sep_conv.depthwise.weight'].double()
+    wp = sd[f'{p}.dep_sep_conv.pointwise.weight'].double()[:, :, 0, 0]
+    s2, t2 = bn_affine64(sd, f'{p}.bn_expanded2')
+    wpf = s2.view(-1, 1) * wp
+    bpf = s2 * sd[f'{p}.dep_sep_conv.pointwise.bias'].double() + t2
+    w2 = sd[f'{p}.expand2.weight'].double()[:, :, 0, 0]
+    s3, t3 = bn_affine64(sd, f'{p}.bn2')
+    w2f = s3.view(-1, 1) * w2
+    b2f = s3 * sd[f'{p}.expand2.bias'].double() + t3
+    out = {'w1': f32(w1f), 'w1_bwd': f32(w1f.t()), 'b1': f32(b1f),
+           'wd': f32(dw_layout(wd)), 'wd_bwd': f32(dw_layout(wd, flip=True)), 'bd': f32(sd[f'{p}.dep_sep_conv.depthwise.bias'].double()),
+           'wp': f32(wpf), 'wp_bwd': f32(wpf.t()), 'bp': f32(bpf),
+           'w2': f32(w2f), 'w2_bwd': f32(w2f.t()), 'b2': f32(b2f)}
+    out.update(_nd_se(sd, f'{p}.squeeze_excitation'))
+    if cell.up:
+        ws = sd[f'{p}.skip.1.weight'].double()[:, :, 0, 0]
+        out['ws'] = f32(ws)
+        out['ws_bwd'] = f32(ws.t())
+        out['bs'] = f32(sd[f'{p}.skip.1.bias'].double())
+    return out
+
+
 def _se(sd: SD, prefix: str) -> dict:
     return {'se_w1': f32(sd[f'{prefix}.linear_1.weight']), 'se_b1': f32(sd[f'{prefix}.linear_1.bias']),
             'se_w2': f32(sd[f'{prefix}.linear_2.weight']), 'se_b2': f32(sd[f'{prefix}.linear_2.bias'])}

@@ -1,0 +1,162 @@
+"""
+GPU parity of the competitor defenders (src/experiments/load_defense.py:95-124):
+  * ND-VAE (`NDVaeDefenseModel` over `Defence_NVAE`): the HIP engine against goldens produced by the REFERENCE's own modules
+    (tests/golden/make_ndvae_golden.py) — purified image at 1e-3, input gradient through the purifier on every element given the
+    engine's decisions — and, with a classifier behind it, against the oracle; through `load(args)` with `--defense_type ND-VAE`.
+"""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd.engine import Engine   # noqa: E402
+from gen_adversarial_amd.ndvae_spec import build_ndvae_spec, init_ndvae_h, init_ndvae_state_dict   # noqa: E402
+from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict   # noqa: E402
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   # noqa: E402
+
+DEV = 'cuda:0'
+PRECISIONS = [('fp32', 2e-4), ('bf16x3', 1e-3)]
+
+
+def golden():
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ndvae.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def _case(g, case):
+    cfg = {str(k): int(v) for k, v in zip(g[f'{case}.cfg_keys'], g[f'{case}.cfg_vals'])}
+    t = lambda k: torch.from_numpy(g[f'{case}.{k}'])                                     # noqa: E731
+    spec = build_ndvae_spec(cfg)
+    return cfg, spec, init_ndvae_state_dict(cfg, int(g[f'{case}.seed'])), t, [t(f'eps{i}') for i in range(len(spec.latent_shapes))]
+
+
+def _engine(cfg, spec, sd, h, rows, rep, noise_std, precision, classifier='vgg'):
+    D = cfg['input_dim']
+    if classifier == 'vgg':
+        cspec, csd = build_vgg_spec(10, 16), init_vgg_state_dict(10, 16, 3)
+    else:
+        cspec, csd = build_resnet_spec(4, 8, (1, 1, 1, 1)), init_resnet_state_dict(4, 8, 3, (1, 1, 1, 1))
+    eng = Engine.bare(rows, device=DEV, precision=precision, rep=rep, resolution=(3, D, D), alphas=[], noise_eps=noise_std)
+    eng.build_ndvae_defense(sd, spec, h, csd, cspec)
+    return eng, csd, cspec
+
+
+def _fill(eng, x, noise, noise_std, eps):
+    eng.x_in.copy_(x.to(DEV))
+    eng.noise.copy_(noise.to(DEV))
+    eng.noise_coef.fill_(noise_std)
+    for dst, src in zip(eng.eps, eps):
+        dst.copy_(src.to(DEV))
+
+
+@pytest.mark.parametrize('case', ['A', 'B'])
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
+def test_ndvae_purifier_matches_the_reference_golden(case, precision, tol):
+    from oracle import ndvae_oracle as N
+    g = golden()
+    cfg, spec, sd, t, eps = _case(g, case)
+    std = float(g[f'{case}.noise_std'])
+    x = t('x')
+    eng, _, _ = _engine(cfg, spec, sd, t('h'), x.shape[0], 1, std, precision)
+    _fill(eng, x, t('noise'), std, eps)
+    eng.forward()
+    e_p = (eng.purified.cpu() - t('purified')).abs().max().item()
+    eng.dpurified.copy_(t('cot').to(DEV))
+    eng.backward(from_logits=False, from_purified=True)
+    gx = t('gx')
+    e_g = (eng.dx.cpu() - gx).abs().max().item() / gx.abs().max().item()
+    print(f'   ND-VAE case {case} [{precision}]: purified {e_p:.2e}, input gradient {e_g:.2e} of max |g| {gx.abs().max().item():.2e}')
+    assert e_p < tol
+    # the SE hidden ReLUs and the mixture head's clamps are kinks: every element given the engine's decisions, and the reference's
+    # own numbers on the rows this machine's oracle reproduces (tests/gradcheck.py)
+    from gradcheck import assert_grad_given_engine_decisions
+    xo = x.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad((N.ndvae_purify(sd, spec, xo, t('noise'), std, eps, t('h')) * t('cot')).sum(), [xo])
+    assert_grad_given_engine_decisions(
+        eng, lambda v: (N.ndvae_purify(sd, spec, v, t('noise'), std, eps, t('h')) * t('cot')).sum(), x, eng.dx, 1e-3,
+        f'ND-VAE input gradient vs the reference golden, case {case} [{precision}]', golden=(gx, g0), max_margin=1e-3)
+
+
+@pytest.mark.parametrize('classifier', ['vgg', 'resnet'])
+def test_ndvae_defender_with_classifier_matches_the_oracle(classifier):
+    """NDVaeDefenseModel.forward = classifier(purify(x)) (purification_model.py:28-31) under EoT 2, logits and input gradient"""
+    from oracle import defender_oracle as D
+    from oracle import ndvae_oracle as N
+    cfg = {'x_channels': 3, 'encoding_channels': 8, 'pre_proc_groups': 2, 'scales': 2, 'groups': 1, 'cells': 2, 'input_dim': 32}
+    if classifier == 'resnet':
+        cfg['input_dim'] = 64                                 # the ResNet stem + max-pool need a few pixels
+        cfg['pre_proc_groups'] = 2
+    spec = build_ndvae_spec(cfg)
+    sd, h = init_ndvae_state_dict(cfg, 21), init_ndvae_h(cfg, 22)
+    rows, rep, std = 4, 2, 0.07
+    gen = torch.Generator().manual_seed(5)
+    Dm = cfg['input_dim']
+    x = torch.rand(rows // rep, 3, Dm, Dm, generator=gen)
+    noise = torch.randn(rows, 3, Dm, Dm, generator=gen)
+    eps = [torch.randn(rows, c, r, r, generator=gen) for c, r in spec.latent_shapes]
+    eng, csd, cspec = _engine(cfg, spec, sd, h, rows, rep, std, 'fp32', classifier)
+
+    def oracle(v):
+        pur = N.ndvae_purify(sd, spec, v.repeat_interleave(rep, dim=0), noise, std, eps, h)
+        return (D.classifier_call(csd, cspec, pur) if classifier == 'vgg' else D.resnet_classifier_call(csd, cspec, pur)), pur
+    xr = x.clone().requires_grad_(True)
+    lo, pur = oracle(xr)
+    cot = torch.randn(lo.shape, generator=gen)
+    _fill(eng, x, noise, std, eps)
+    eng.forward()
+    e_p, e_l = (eng.purified.cpu() - pur).abs().max().item(), (eng.logits.cpu() - lo).abs().max().item()
+    print(f'   ND-VAE + {classifier}: purified {e_p:.2e} logits {e_l:.2e} (|logits| {lo.abs().max().item():.2f})')
+    assert e_p < 2e-4 and e_l < 2e-4 * max(1.0, lo.abs().max().item())
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda v: (oracle(v)[0] * cot).sum(), x, eng.dx, 1e-3,
+                                       f'ND-VAE + {classifier} input gradient', min_matched=4, max_margin=1e-3)
+
+
+def test_ndvae_through_the_reference_api(tmp_path):
+    """--defense_type ND-VAE through load(args) with the yaml keys of configs/competitor_ndvae_ids.yaml (load_defense.py:108-124):
+    EoT-mean logits against the oracle under fixed draws, get_purified, autograd to the input."""
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import defender_oracle as D
+    from oracle import ndvae_oracle as N
+    cfg = {'x_channels': 3, 'encoding_channels': 4, 'pre_proc_groups': 2, 'scales': 1, 'groups': 2, 'cells': 1, 'input_dim': 64}
+    spec = build_ndvae_spec(cfg)
+    sd = init_ndvae_state_dict(cfg, 31)
+    vsd = init_vgg_state_dict(100, 16, 32)
+    torch.save(sd, tmp_path / 'ndvae.pt')
+    torch.save({'state_dict': vsd}, tmp_path / 'vgg.pt')
+    y = {'classifier_path': str(tmp_path / 'vgg.pt'), 'autoencoder_path': str(tmp_path / 'ndvae.pt'), 'noise_std': 0.05,
+         'x_channels': 3, 'pre_proc_groups': 2, 'encoding_channels': 4, 'scales': 1, 'groups': 2, 'cells': 1}
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump(y, f)
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='ids', defense_type='ND-VAE', eot_steps=2, device=DEV))
+    h = model.model.purifier.h
+    gen = torch.Generator().manual_seed(8)
+    x = torch.rand(1, 3, 64, 64, generator=gen)
+    noise = torch.randn(2, 3, 64, 64, generator=gen)
+    eps = [torch.randn(2, c, r, r, generator=gen) for c, r in spec.latent_shapes]
+    xr = x.clone().requires_grad_(True)
+    pur = N.ndvae_purify(sd, spec, xr.repeat_interleave(2, dim=0), noise, 0.05, eps, h)
+    lo = D.classifier_call(vsd, build_vgg_spec(100, 16), pur).mean(dim=0, keepdim=True)
+    (g0,) = torch.autograd.grad(lo[0, 3], [xr])
+    model.model.fixed_noise([e.to(DEV) for e in eps], noise.to(DEV))
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        out = model(xd)
+        assert out.shape == (1, 100) and (out.cpu() - lo).abs().max().item() < 2e-4 * max(1.0, lo.abs().max().item())
+        (g1,) = torch.autograd.grad(out[0, 3], [xd])
+        assert (g1.cpu() - g0).abs().max().item() < 1e-3 * max(g0.abs().max().item(), 1e-30)
+        model.model.fixed_noise([e[:1].to(DEV) for e in eps], noise[:1].to(DEV))
+        p1 = model.get_purified(x.to(DEV))
+        assert p1.shape == (1, 3, 64, 64) and (p1.cpu() - pur[:1]).abs().max().item() < 2e-4
+    finally:
+        model.model.fixed_noise(None, None)
