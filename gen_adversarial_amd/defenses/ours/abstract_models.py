@@ -41,6 +41,8 @@ class _EngineFn(torch.autograd.Function):
             return logits, eng.purified.clone()
         if want_purified and getattr(eng, 'purified_s2d', None) is not None:     # e4e defender: classifier-layout image
             return logits, eng.purified_nchw()
+        if want_purified and getattr(eng, 'purified_nhwc', None) is not None:    # A-VAE: the to_rgb output is the NHWC image
+            return logits, eng.purified_nhwc.t[..., :3].permute(0, 3, 1, 2).contiguous()
         return logits, x.new_zeros(())
 
     @staticmethod

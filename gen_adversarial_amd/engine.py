@@ -29,13 +29,14 @@ from .engine_core import (IMG_LD, RES_SCALE, TUNE_FILE, WS_FLOATS, Act, WeightSt
                           tune_cache)
 from .engine_classifiers import ClassifierBuilder
 from .engine_e4e import E4EBuilder
+from .engine_avae import AvaeBuilder
 from .engine_ndvae import NdvaeBuilder
 from .engine_nvae import NvaeBuilder
 from .engine_stylegan import StyleGanBuilder
 from .engine_trans import TransBuilder
 
 
-class Engine(NvaeBuilder, NdvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransBuilder):
+class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuilder, StyleGanBuilder, TransBuilder):
     # decoder cells whose shape ga_dec_cell takes run as one fused launch per direction (GA_FUSE_DEC_CELL=0: the three
     # unfused launches, same numbers bit for bit — kept for A/B profiles and for the shapes the fused kernel refuses)
     fuse_dec_cells = os.environ.get('GA_FUSE_DEC_CELL', '1') != '0'

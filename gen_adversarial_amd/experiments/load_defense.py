@@ -4,11 +4,10 @@ Config / factory layer with the reference's surface (src/experiments/load_defens
 `interpolation_alphas`, `alpha_attenuation`, `initial_noise_eps`, `gaussian_blur_input`), sets `args.image_size`,
 `args.attacks` and attaches `defense_model.get_purified`.
 
-Built: experiment 'ids' with defense_type 'base' | 'trades' (classifier only), 'ablation' (noise / blur) and 'ours'
-(NVAE purifier); experiment 'gender' (ResNet-50, 256x256) with 'base' | 'trades' | 'ablation' | 'ours' (e4e + StyleGAN2
-purifier); experiment 'cars' (ResNeXt-50, 128x128) with 'base' | 'trades' | 'ablation'; the reference's
-attack sets (DeepFool, C&W, AutoAttack) plus `args.pgd` (PGD-Linf).
-Everything else raises NotImplementedError, exactly like an unknown experiment does in the reference (:75,:144).
+Built: every defense_type of the reference for every experiment — 'base' | 'trades' (classifier only), 'ablation' (noise /
+blur), 'ours' (ids: NVAE; gender: e4e + StyleGAN2; cars: Style-Transformer + StyleGAN2) and the competitors 'A-VAE' / 'ND-VAE'
+(load_defense.py:95-124) — plus the reference's attack sets (DeepFool, C&W, AutoAttack) and `args.pgd` (PGD-Linf).
+An unknown experiment or defense type raises NotImplementedError, like in the reference (:75,:144).
 """
 from argparse import Namespace
 
@@ -17,6 +16,7 @@ import yaml
 from ..attacks.l2_attacks import AutoAttack, CW, DeepFool
 from ..attacks.pgd import PGDLinf
 from ..defenses.ablations.models import GaussianBlurDefenseModel, GaussianNoiseDefenseModel
+from ..defenses.competitors.a_vae import AVaeDefenseModel, load_AVAE
 from ..defenses.competitors.nd_vae import NDVaeDefenseModel, load_NDVAE
 from ..defenses.ours.models import (CarsTypeClassifier, CelebaGenderClassifier, CelebaIdentityClassifier,
                                    E4EStyleGanDefenseModel, NVAEDefenseModel, TransStyleGanDefenseModel)
@@ -74,6 +74,12 @@ def load(args: Namespace):
             defense_model = GaussianNoiseDefenseModel(base_classifier, 2. if args.experiment == 'ids' else 4.)
         else:
             defense_model = GaussianBlurDefenseModel(base_classifier)
+        defense_model = EoTWrapper(defense_model, args.eot_steps)
+        defense_model.get_purified = lambda x: defense_model.model.purify(x)
+    elif args.defense_type == 'A-VAE':
+        # load_defense.py:95-106: StyledGenerator(args.image_size), AVaeDefenseModel(base_classifier, a_vae, kernel_size)
+        a_vae = load_AVAE(d_params.autoencoder_path, args.image_size)
+        defense_model = AVaeDefenseModel(base_classifier, a_vae, d_params.kernel_size)
         defense_model = EoTWrapper(defense_model, args.eot_steps)
         defense_model.get_purified = lambda x: defense_model.model.purify(x)
     elif args.defense_type == 'ND-VAE':

@@ -387,6 +387,26 @@ typedef struct ga_dec_cell_desc {
 int ga_dec_cell(const ga_dec_cell_desc* d, void* stream);
 int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_dec_cell takes the shape */
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pieces of the A-VAE competitor purifier (src/defenses/competitors/a_vae; csrc/avae.hip), selected by `mode`:
+ *   GA_AVAE_ADAIN     forward : u = lrelu_0.2(x + b[c] * a[n,p]);  y = c[n,c] * (u - mean_p u) * rstd + c[n,C+c];  y2 = stats [N,C,2]
+ *                     backward: dy -> y = d/dx [N,P,C], y2 = (d gamma | d beta) [N,2C]; s = the forward's stats
+ *                     x: [N,P,C]; a: noise [N,P] or NULL (then b NULL); b: [C]; c: style output [N,2C] = (gamma | beta)
+ *   GA_AVAE_AVGPOOL   k x k / stride k mean, x [N,H,W,C] -> y [N,H/k,W/k,C]; backward dy [N,H/k,W/k,C] -> y [N,H,W,C]
+ *   GA_AVAE_PIXELNORM x [N,C]: y = x * rsqrt(mean_c x^2 + 1e-8); backward (dy, x) -> y = dx
+ *   GA_AVAE_SAMPLE    x = t [N,P,2C], a = eps [N,C,P] (NCHW): z[n,p,c] = lrelu(t[..c]) + eps * exp(0.5 lrelu(t[..C+c])) * f0;
+ *                     backward dy = dz [N,P,C] -> y = dt [N,P,2C]
+ * ------------------------------------------------------------------------------------------------------------------ */
+enum { GA_AVAE_ADAIN = 0, GA_AVAE_AVGPOOL = 1, GA_AVAE_PIXELNORM = 2, GA_AVAE_SAMPLE = 3 };
+typedef struct ga_avae_desc {
+    const float* x; const float* a; const float* b; const float* c; const float* s; const float* dy;
+    float* y; float* y2;
+    int mode, backward;
+    int N, P, C, k, H, W;
+    float f0; int _reserved;
+} ga_avae_desc;
+int ga_avae(const ga_avae_desc* d, void* stream);
+
 /* On-box peak microbenchmarks for bench.py's roofline.frac_of_measured_peak; not part of the path.
  * ga_microbench_hbm_copy: dst = src, n_floats % 4 == 0, 16 B per lane (2 * 4 * n_floats bytes of traffic per call).
  * ga_microbench_mfma_bf16: a bare v_mfma_f32_32x32x16_bf16 loop on pseudo-random operands, `blocks` workgroups of 4 waves;
@@ -497,7 +517,8 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_AXPBY = 11, GA_OP_BLUR = 12, GA_OP_REP_SUM = 13, GA_OP_INTERLEAVE2 = 14, GA_OP_MAXPOOL3S2 = 15,
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
                   GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21, GA_OP_PIXELNORM = 22, GA_OP_LATENT_MIX = 23,
-                  GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27, GA_OP_DEC_CELL = 28 };
+                  GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27, GA_OP_DEC_CELL = 28,
+                  GA_OP_AVAE = 29 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -509,7 +530,7 @@ typedef struct ga_op {
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
         ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub; ga_latent_mix_desc lm; ga_pool_denorm_desc pd;
-        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc; ga_dec_cell_desc dc;
+        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc; ga_dec_cell_desc dc; ga_avae_desc av;
         struct { const float* x; float* y; long rows; int C; } pn;
     } u;
 } ga_op;

@@ -160,3 +160,129 @@ def test_ndvae_through_the_reference_api(tmp_path):
         assert p1.shape == (1, 3, 64, 64) and (p1.cpu() - pur[:1]).abs().max().item() < 2e-4
     finally:
         model.model.fixed_noise(None, None)
+
+
+# ------------------------------------------------------------------------------------------------------------------ A-VAE
+from gen_adversarial_amd.avae_spec import build_avae_spec, init_avae_state_dict   # noqa: E402
+
+
+def _avae_engine(spec, sd, k, rows, rep, precision, classifier='vgg'):
+    D = spec.output_size
+    if classifier == 'vgg':
+        cspec, csd = build_vgg_spec(10, 16), init_vgg_state_dict(10, 16, 3)
+    else:
+        cspec, csd = build_resnet_spec(4, 8, (1, 1, 1, 1)), init_resnet_state_dict(4, 8, 3, (1, 1, 1, 1))
+    eng = Engine.bare(rows, device=DEV, precision=precision, rep=rep, resolution=(3, D, D), alphas=[])
+    eng.build_avae_defense(sd, spec, k, csd, cspec)
+    return eng, csd, cspec
+
+
+def _avae_fill(eng, x, eps, noise):
+    eng.x_in.copy_(x.to(DEV))
+    eng.eps[0].copy_(eps.to(DEV))
+    for dst, src in zip(eng.eps[1:], noise):
+        dst.copy_(src.to(DEV))
+
+
+@pytest.mark.parametrize('precision,tol', PRECISIONS)
+def test_avae_purifier_matches_the_reference_golden(precision, tol):
+    """StyledGenerator(64) + AVaeDefenseModel.purify at the reference's full width against the golden produced by the reference's
+    own modules (tests/golden/make_avae_golden.py): purified image, and its input gradient for a cotangent on the purified image
+    (through the encoder skip AND through the style MLP / AdaIN path) given the engine's LeakyReLU decisions."""
+    from oracle import avae_oracle as A
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'avae.npz'))
+    g = {k: z[k] for k in z.files}
+    size, k = int(g['size']), int(g['kernel_size'])
+    spec = build_avae_spec(size)
+    sd = init_avae_state_dict(size, int(g['seed']))
+    t = lambda key: torch.from_numpy(g[key])                                             # noqa: E731
+    noise = [t(f'noise{i}') for i in range(len(spec.blocks))]
+    x = t('x')
+    eng, _, _ = _avae_engine(spec, sd, k, x.shape[0], 1, precision)
+    _avae_fill(eng, x, t('eps'), noise)
+    eng.forward()
+    pur = eng.purified_nhwc.t[..., :3].permute(0, 3, 1, 2).cpu()
+    ref = t('purified')
+    e_p = (pur - ref).abs().max().item() / ref.abs().max().item()
+    img = eng._purified_grad_nhwc
+    img.g.zero_()
+    img.g[..., :3].copy_(t('cot').permute(0, 2, 3, 1).to(DEV))
+    eng.bwd.run(eng.stream(), start=eng.bwd_split)
+    gx = t('gx')
+    e_g = (eng.dx.cpu() - gx).abs().max().item() / gx.abs().max().item()
+    print(f'   A-VAE [{precision}]: purified {e_p:.2e} of {ref.abs().max().item():.2f}, input gradient {e_g:.2e} of max |g| {gx.abs().max().item():.2e}')
+    assert e_p < tol
+    from gradcheck import assert_grad_given_engine_decisions
+    xo = x.clone().requires_grad_(True)
+    (g0,) = torch.autograd.grad((A.avae_purify(sd, spec, xo, k, t('eps'), noise) * t('cot')).sum(), [xo])
+    assert_grad_given_engine_decisions(
+        eng, lambda v: (A.avae_purify(sd, spec, v, k, t('eps'), noise) * t('cot')).sum(), x, eng.dx, 1e-3,
+        f'A-VAE input gradient vs the reference golden [{precision}]', golden=(gx, g0), max_margin=1e-3, min_matched=8)
+
+
+@pytest.mark.parametrize('classifier,size,k', [('vgg', 64, 2), ('resnet', 128, 4)])
+def test_avae_defender_with_classifier_matches_the_oracle(classifier, size, k):
+    """AVaeDefenseModel.forward = classifier(purify(x)) (purification_model.py:22-25) under EoT 2 at 1/8 width: logits and the
+    input gradient; 128-px output = the cars layout (one more fused up-sampling block), 64 px = ids"""
+    from oracle import avae_oracle as A
+    from oracle import defender_oracle as D
+    spec = build_avae_spec(size, 8)
+    sd = init_avae_state_dict(size, 51, 8)
+    rows, rep = 4, 2
+    gen = torch.Generator().manual_seed(6)
+    x = torch.rand(rows // rep, 3, size, size, generator=gen)
+    eps = torch.randn(rows, spec.c512, 4, 4, generator=gen)
+    noise = [torch.randn(rows, 1, b.res, b.res, generator=gen) for b in spec.blocks]
+    eng, csd, cspec = _avae_engine(spec, sd, k, rows, rep, 'fp32', classifier)
+
+    def oracle(v):
+        pur = A.avae_purify(sd, spec, v.repeat_interleave(rep, dim=0), k, eps, noise)
+        return D.classifier_call(csd, cspec, pur) if classifier == 'vgg' else D.resnet_classifier_call(csd, cspec, pur)
+    xr = x.clone().requires_grad_(True)
+    lo = oracle(xr)
+    cot = torch.randn(lo.shape, generator=gen)
+    _avae_fill(eng, x, eps, noise)
+    eng.forward()
+    e_l = (eng.logits.cpu() - lo).abs().max().item()
+    print(f'   A-VAE + {classifier} @ {size}: logits {e_l:.2e} (|logits| {lo.abs().max().item():.2f})')
+    assert e_l < 2e-4 * max(1.0, lo.abs().max().item())
+    eng.dlogits.view_as(eng.logits).copy_(cot.to(DEV))
+    eng.backward()
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda v: (oracle(v) * cot).sum(), x, eng.dx, 1e-3,
+                                       f'A-VAE + {classifier} input gradient', min_matched=8, max_margin=1e-3)
+
+
+def test_avae_through_the_reference_api(tmp_path):
+    """--defense_type A-VAE through load(args) with the yaml keys of configs/competitor_avae_ids.yaml (load_defense.py:95-106)"""
+    from gen_adversarial_amd.experiments.load_defense import load
+    from oracle import avae_oracle as A
+    from oracle import defender_oracle as D
+    spec = build_avae_spec(64)
+    sd = init_avae_state_dict(64, 61)
+    vsd = init_vgg_state_dict(100, 16, 62)
+    torch.save(sd, tmp_path / 'avae.pt')
+    torch.save({'state_dict': vsd}, tmp_path / 'vgg.pt')
+    with open(tmp_path / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(tmp_path / 'vgg.pt'), 'autoencoder_path': str(tmp_path / 'avae.pt'), 'kernel_size': 2}, f)
+    args, model = load(Namespace(config=str(tmp_path / 'cfg.yaml'), experiment='ids', defense_type='A-VAE', eot_steps=2, device=DEV))
+    gen = torch.Generator().manual_seed(9)
+    x = torch.rand(1, 3, 64, 64, generator=gen)
+    eps = torch.randn(2, 512, 4, 4, generator=gen)
+    noise = [torch.randn(2, 1, b.res, b.res, generator=gen) for b in spec.blocks]
+    xr = x.clone().requires_grad_(True)
+    pur = A.avae_purify(sd, spec, xr.repeat_interleave(2, dim=0), 2, eps, noise)
+    lo = D.classifier_call(vsd, build_vgg_spec(100, 16), pur).mean(dim=0, keepdim=True)
+    (g0,) = torch.autograd.grad(lo[0, 5], [xr])
+    model.model.fixed_noise([eps.to(DEV)] + [n.to(DEV) for n in noise], None)
+    try:
+        xd = x.to(DEV).requires_grad_(True)
+        out = model(xd)
+        assert out.shape == (1, 100) and (out.cpu() - lo).abs().max().item() < 1e-3 * max(1.0, lo.abs().max().item())
+        (g1,) = torch.autograd.grad(out[0, 5], [xd])
+        assert (g1.cpu() - g0).abs().max().item() < 2e-3 * max(g0.abs().max().item(), 1e-30)
+        model.model.fixed_noise([eps[:1].to(DEV)] + [n[:1].to(DEV) for n in noise], None)
+        p1 = model.get_purified(x.to(DEV))
+        assert p1.shape == (1, 3, 64, 64) and (p1.cpu() - pur[:1]).abs().max().item() < 1e-3 * max(1.0, pur.abs().max().item())
+    finally:
+        model.model.fixed_noise(None, None)

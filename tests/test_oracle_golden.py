@@ -425,3 +425,21 @@ def test_ndvae_oracle_matches_the_reference_golden(case):
     assert (pur - t('purified')).abs().max().item() < 1e-5
     (gx,) = torch.autograd.grad((pur * t('cot')).sum(), [x])
     assert (gx - t('gx')).abs().max().item() < 1e-5 * max(1.0, t('gx').abs().max().item())
+
+
+def test_avae_oracle_matches_the_reference_golden():
+    """the A-VAE competitor purifier (StyledGenerator(64) + AVaeDefenseModel.purify) restated in
+    oracle/avae_oracle.py against the reference's own modules (tests/golden/make_avae_golden.py)."""
+    from gen_adversarial_amd.avae_spec import build_avae_spec, init_avae_state_dict
+    from oracle import avae_oracle as A
+    g = load_golden('avae.npz')
+    spec = build_avae_spec(int(g['size']))
+    sd = init_avae_state_dict(int(g['size']), int(g['seed']))
+    noise = [torch.from_numpy(g[f'noise{i}']) for i in range(len(spec.blocks))]
+    x = torch.from_numpy(g['x']).clone().requires_grad_(True)
+    pur = A.avae_purify(sd, spec, x, int(g['kernel_size']), torch.from_numpy(g['eps']), noise)
+    ref = torch.from_numpy(g['purified'])
+    assert (pur - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    (gx,) = torch.autograd.grad((pur * torch.from_numpy(g['cot'])).sum(), [x])
+    rg = torch.from_numpy(g['gx'])
+    assert (gx - rg).abs().max().item() < 1e-5 * max(1.0, rg.abs().max().item())
