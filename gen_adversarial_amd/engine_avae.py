@@ -63,6 +63,9 @@ class AvaeBuilder:
         self.conv(self.fwd, name + '.style', style_pre.t, fc['w'], gb.t, bias=fc['b'], K=1, pro_scale=sl, pro_shift=sl, flags=L.GA_CONV_PRO_PRELU)
         y = Act(self, R, t.h, t.w, C, name)
         stats = self.alloc((R, C, 2))
+        if not hasattr(self, '_avae_kinks'):
+            self._avae_kinks = []
+        self._avae_kinks.append((t, noise, wn))            # the LeakyReLU decides on t + wn * noise (parity tests replay it)
         self._avae_op(self.fwd, name, L.GA_AVAE_ADAIN, x=t.t, a=noise, b=wn, c=gb.t, y=y.t, y2=stats, N=R, P=t.h * t.w, C=C, backward=0)
 
         def backward():
@@ -73,6 +76,11 @@ class AvaeBuilder:
                            flags=L.GA_CONV_DACT_PRELU)
         self._bwd_steps.append(backward)
         return y
+
+    def extra_kink_tensors(self) -> List[torch.Tensor]:
+        """the tensors whose signs the generator's LeakyReLUs decided on in the last forward ([R, H, W, C] each): the engine stores
+        the conv outputs BEFORE the noise injection, the decision is taken after it (tests/gradcheck.py replays it in the oracle)"""
+        return [t.t + wn.view(1, 1, 1, -1) * nz.view(t.n, t.h, t.w, 1) for t, nz, wn in getattr(self, '_avae_kinks', [])]
 
     def build_avae_defense(self, asd, aspec: AvaeSpec, kernel_size: int, csd, cspec):
         """AVaeDefenseModel.forward (purification_model.py:22-25) as one forward / backward plan pair.  Caller-visible: x_in, eps =
@@ -261,8 +269,8 @@ class AvaeBuilder:
         # ---- to_rgb (1x1) and anti_transform (x + 1) / 2
         n_purifier_steps = None
         if isinstance(cspec, ResNetSpec):
-            rgb = self.devd('avae.to_rgb.raw', lambda: F.pad_conv_out(_eq_conv(asd, 'generator.to_rgb'), 3, IMG_LD))
-            raw = Act(self, R, D, D, IMG_LD, 'avae.rgb')
+            rgb = self.devd('avae.to_rgb.raw', lambda: F.pad_conv_out(_eq_conv(asd, 'generator.to_rgb'), 3, 4))
+            raw = Act(self, R, D, D, 4, 'avae.rgb')              # ga_pool_denorm reads the generated image at a pitch of 4 lanes
             self.conv(self.fwd, 'avae.to_rgb', out.t, rgb['w'], raw.t, bias=rgb['b'], K=1)
             img = Act(self, R, D // 2, D // 2, 4 * IMG_LD, 'purified_s2d')
             pd = L.PoolDenormDesc()

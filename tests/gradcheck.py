@@ -40,6 +40,12 @@ def engine_candidates(eng, rows=None):
         if rows is not None and t.shape[0] == eng.rows:
             t = t[rows]
         out.append(t.permute(0, 3, 1, 2).float().cpu())
+    extra = getattr(eng, 'extra_kink_tensors', None)            # decision tensors the engine does not store as such (A-VAE: conv + noise)
+    for t in (extra() if extra is not None else []):
+        t = t.detach()
+        if rows is not None and t.shape[0] == eng.rows:
+            t = t[rows]
+        out.append(t.permute(0, 3, 1, 2).float().cpu())
     return out
 
 

