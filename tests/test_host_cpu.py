@@ -428,3 +428,47 @@ def test_fused_decoder_cells_are_chosen_by_launch_size():
                      device='meta', dry_run=True, store=store)
         got = sum(isinstance(d, L.DecCellDesc) for d in eng.fwd.descs)
         assert got == want and sum(isinstance(d, L.DecCellDesc) for d in eng.bwd.descs) == want, (rows, got)
+
+
+def test_competitor_defender_plans_build_without_a_gpu():
+    """SURVEY.md §8 row f4 (dry run): the ND-VAE and A-VAE competitor defenders as one plan pair each, with a VGG and with a ResNet
+    behind them; the backward plan replays the classifier first, the purifier's boundary ops last; the specs follow the
+    reference's constructors (channel bookkeeping of Defence_NVAE, block list of StyledGenerator)."""
+    from gen_adversarial_amd.avae_spec import build_avae_spec, init_avae_state_dict
+    from gen_adversarial_amd.ndvae_spec import build_ndvae_spec, init_ndvae_h, init_ndvae_state_dict
+    from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
+    vgg = (build_vgg_spec(10, 16), init_vgg_state_dict(10, 16, 3))
+    res = (build_resnet_spec(4, 8, (1, 1, 1, 1)), init_resnet_state_dict(4, 8, 3, (1, 1, 1, 1)))
+    # ---- ND-VAE: configs/competitor_ndvae_ids.yaml (scales 1, groups 8, cells 2) and _gender.yaml (scales 2, groups 4) shapes
+    ids = build_ndvae_spec({'x_channels': 3, 'encoding_channels': 32, 'pre_proc_groups': 2, 'scales': 1, 'groups': 8, 'cells': 2, 'input_dim': 64})
+    assert (ids.top_channels, ids.top_res, ids.h_shape, ids.latent_shapes) == (128, 16, (128, 16, 16), [(128, 16), (128, 16)])
+    assert len(ids.enc_scales[0]) == 16 and len(ids.dec_scales[0].groups) == 8 and [c.hidden for c in ids.post_cells] == [256, 4096, 128, 1024]
+    gen = build_ndvae_spec({'x_channels': 3, 'encoding_channels': 16, 'pre_proc_groups': 2, 'scales': 2, 'groups': 4, 'cells': 2, 'input_dim': 256})
+    assert gen.latent_shapes == [(128, 32), (128, 32), (64, 64)] and gen.dec_scales[1].up.cout == 64
+    with pytest.raises(ValueError):          # Decoder_tower.h would not meet the encoder's top feature map (torch.cat fails in the reference)
+        build_ndvae_spec({'x_channels': 3, 'encoding_channels': 4, 'pre_proc_groups': 1, 'scales': 2, 'groups': 1, 'cells': 1, 'input_dim': 64})
+    cfg = {'x_channels': 3, 'encoding_channels': 4, 'pre_proc_groups': 2, 'scales': 2, 'groups': 2, 'cells': 2, 'input_dim': 32}
+    spec, sd, h = build_ndvae_spec(cfg), init_ndvae_state_dict(cfg, 1), init_ndvae_h(cfg, 2)
+    for cspec, csd in (vgg, res):
+        eng = Engine.bare(4, device='cpu', dry_run=True, rep=2, resolution=(3, 32, 32), alphas=[], noise_eps=0.1)
+        eng.build_ndvae_defense(sd, spec, h, csd, cspec)
+        f, b = eng.fwd.names, eng.bwd.names
+        assert f[0] == 'image_in' and f.index('nd.stem') < f.index('decoder.samplers.0.sample') < f.index('nd.dml_mean') < len(f) - 1
+        assert b[-1] == 'image_in^T' and b.index('nd.dml_mean^T') >= eng.bwd_split > 0
+        assert sum(isinstance(d, L.SamplerDesc) and d.mode == 1 for d in eng.fwd.descs) == 3
+        assert [tuple(e.shape[1:]) for e in eng.eps] == [(c, r, r) for c, r in spec.latent_shapes] and eng.noise is not None
+    # ---- A-VAE: the three output sizes of the reference (model.py:37-66), skip concatenated at 16 x 16
+    assert [(b_.kind, b_.cin, b_.cout, b_.res, b_.skip) for b_ in build_avae_spec(64).blocks] == [
+        ('initial', 512, 512, 4, False), ('up', 512, 512, 8, False), ('up', 512, 512, 16, False), ('fused', 768, 256, 32, True),
+        ('fused', 256, 128, 64, False)]
+    assert len(build_avae_spec(128).blocks) == 6 and len(build_avae_spec(256).blocks) == 7
+    for size, k in ((64, 2), (128, 4)):
+        aspec, asd = build_avae_spec(size, 8), init_avae_state_dict(size, 1, 8)
+        for cspec, csd in (vgg, res):
+            eng = Engine.bare(4, device='cpu', dry_run=True, rep=2, resolution=(3, size, size), alphas=[])
+            eng.build_avae_defense(asd, aspec, k, csd, cspec)
+            f, b = eng.fwd.names, eng.bwd.names
+            assert f[:2] == ['image_in', 'avae.avgpool'] and b[-2:] == ['avae.avgpool^T', 'image_in^T']
+            assert sum(isinstance(d, L.AvaeDesc) and d.mode == L.GA_AVAE_ADAIN for d in eng.fwd.descs) == 2 * len(aspec.blocks)
+            assert b.index('avae.to_rgb^T') >= eng.bwd_split > 0 and b.index('avae.sample^T') > b.index('generator.progression.0.adain1^T')
+            assert len(eng.eps) == 1 + len(aspec.blocks)
