@@ -185,7 +185,7 @@ class Resize2CropDesc(C.Structure):
 class DecCellDesc(C.Structure):
     _fields_ = [('x', fp), ('w1_hi', fp), ('w1_lo', fp), ('b1', fp), ('wd', fp), ('wd_bwd', fp), ('bd', fp),
                 ('w2_hi', fp), ('w2_lo', fp), ('b2', fp), ('dout', fp), ('pro_scale', fp), ('pro_shift', fp), ('y', fp),
-                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Hd', i32), ('backward', i32), ('act_rep', i32), ('_reserved', i32)]
+                ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Hd', i32), ('backward', i32), ('act_rep', i32), ('variant', i32)]
 
 
 class AvaeDesc(C.Structure):

@@ -26,8 +26,16 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long ga_trace_buf_halo[8 * 8192];
 #define GA_HSTAMP(i)                                                                                     \
     if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) ga_trace_buf_halo[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
+// K-loop anatomy (wave 0 of every workgroup): clocks in the MFMA part of the steps, in the chunk-boundary patch staging and in
+// the step barrier, summed over the loop into trace slots 5..7
+#define GA_HT0 unsigned long long hsum[3] = {0, 0, 0}; unsigned long long hprev = __builtin_amdgcn_s_memtime();
+#define GA_HT(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long long tn = __builtin_amdgcn_s_memtime(); hsum[i] += tn - hprev; hprev = tn; __builtin_amdgcn_sched_barrier(0); }
+#define GA_HTEND if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) { for (int i = 0; i < 3; ++i) ga_trace_buf_halo[blockIdx.x * 8 + 5 + i] = hsum[i]; }
 #else
 #define GA_HSTAMP(i)
+#define GA_HT0
+#define GA_HT(i)
+#define GA_HTEND
 #endif
 
 constexpr int HK = 32;          // channels per chunk
@@ -264,6 +272,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
     __syncthreads();
     GA_HSTAMP(2)
     int tap = 0, tapoff = 0, chunk = cb;
+    GA_HT0
     // step s: weight stage s & 1 feeds the MFMAs; register set s & 1 (drained into that stage one step ago) takes the
     // loads of step s+2; set (s+1) & 1, loaded during step s-1, is written to the other stage behind the MFMAs
     auto step = [&](const int par, const int s) __attribute__((always_inline)) {
@@ -280,6 +289,7 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                  // one LDS write ...
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                  // ... per two trailing MFMAs
         }
+        GA_HT(0)
         ++tap;
         tapoff += LDH;                                      // next column of the window ...
         if (tap == 3 || tap == 6) tapoff += g.RS - 3 * LDH;      // ... or the start of its next row
@@ -291,13 +301,16 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
                 finish_patch();
                 if (chunk + 1 < ce) issue_patch(chunk + 1);
             }
+            GA_HT(1)
         }
         if (!(GA_EXP & 4)) __syncthreads();
+        GA_HT(2)
     };
     for (int s = 0; s < nsteps; s += 2) {
         step(0, s);
         if (s + 1 < nsteps) step(1, s + 1);
     }
+    GA_HTEND
     __syncthreads();
     GA_HSTAMP(3)
 

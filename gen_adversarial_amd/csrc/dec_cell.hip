@@ -34,7 +34,7 @@ constexpr int DC_LDB = 40;      // bf16 per pixel of a bf16 LDS plane (80 B rows
 // -DGA_DC_TRACE (make dctrace -> libga_ops_dctrace.so, tools/dec_cell_trace.py): per-phase shader-clock sums of the chunk
 // loop, lane 0 of every wave of workgroup 0
 #ifdef GA_DC_TRACE
-__device__ unsigned long long ga_dc_trace_buf[4 * 16];
+__device__ unsigned long long ga_dc_trace_buf[8 * 16];
 #define DC_T0 unsigned long long tsum[12] = {}; unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #define DC_T(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[i] += tn - tprev; tprev = tn; }
 #define DC_TEND if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i = 0; i < 12; ++i) ga_dc_trace_buf[(threadIdx.x >> 6) * 16 + i] = tsum[i]; }
@@ -169,16 +169,16 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 // 32 rows (the chunk's hidden channels) x C columns, LDS pitch C + 8 elements.  Otherwise (the project conv W2, [C][Hd]):
 // C rows x the chunk's 32 columns, LDS pitch 40.  Both pitches are 16 B mod 256 B: the 16-B fragment reads of 16 lanes
 // with consecutive rows fall on 16 distinct bank slots.  256 threads move 16-B pieces; NP pieces per thread and array.
-template <int C, bool ROWS32>
+template <int C, bool ROWS32, int NTHR = 256>
 struct w_chunk {
-    static constexpr int NP = C / 64;
+    static constexpr int NP = 4 * C / NTHR;                          // 4 C 16-byte pieces per array, NTHR threads
     static constexpr int PITCH = ROWS32 ? C + 8 : 40;
     static constexpr int ELEMS = (ROWS32 ? 32 : C) * PITCH;          // bf16 elements of one LDS copy (hi or lo)
     uintx4 hi[NP], lo[NP];
     __device__ __forceinline__ void issue(const __bf16* gh, const __bf16* gl, const int ld, const int h0, const int tid) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NTHR * k;
             const size_t o = ROWS32 ? (size_t)(h0 + q / (C / 8)) * ld + (q % (C / 8)) * 8 : (size_t)(q >> 2) * ld + h0 + (q & 3) * 8;
             hi[k] = *reinterpret_cast<const uintx4*>(gh + o);
             lo[k] = *reinterpret_cast<const uintx4*>(gl + o);
@@ -187,7 +187,7 @@ struct w_chunk {
     __device__ __forceinline__ void store(__bf16* sh, __bf16* sl, const int tid) const {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NTHR * k;
             const int o = ROWS32 ? (q / (C / 8)) * PITCH + (q % (C / 8)) * 8 : (q >> 2) * PITCH + (q & 3) * 8;
             *reinterpret_cast<uintx4*>(sh + o) = hi[k];
             *reinterpret_cast<uintx4*>(sl + o) = lo[k];
@@ -218,12 +218,16 @@ __device__ __forceinline__ void interleave_mfma_valu() {
 //   -- barrier 2 --   W2(ch+1): registers -> LDS
 // The global loads behind the register -> LDS stores are issued at the top of the iteration.  Chunk indices past the end
 // are clamped: the last iteration's GEMM1 / P1 write are wasted work beside phases that run anyway.
-template <int C, int TMW>
-__global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
-    constexpr int M = 128 * TMW, KS = C / 16, NT = C / 32, SW = 4 * TMW;
+// NW waves per workgroup (4: one per SIMD, the whole register file for x + accumulators; 8: two per SIMD at half the rows per wave —
+// the vector-ALU phases of one wave then run beside the other's MFMAs, and a SIMD issues a vector instruction every 2 clocks
+// instead of every 4 (one wave alone cannot: MI355X_MICROARCH.md, 'vector-instruction ISSUE cost'))
+template <int C, int TMW, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_fwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
+    constexpr int NTHR = 64 * NW;
+    constexpr int M = 32 * TMW * NW, KS = C / 16, NT = C / 32, SW = M / (NTHR / 8);
     constexpr int BH = TMW == 2 ? 2 : 1, BW = SW / BH;      // this thread's SW depthwise outputs: BH rows x BW columns
-    using WA = w_chunk<C, true>;
-    using WB = w_chunk<C, false>;
+    using WA = w_chunk<C, true, NTHR>;
+    using WB = w_chunk<C, false, NTHR>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wS = smem;                                                   // [25][32] taps of the chunk
     float* P1 = smem + 25 * DC_CH;                                      // framed fp32 plane
@@ -244,6 +248,11 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
     const __bf16* g1l = reinterpret_cast<const __bf16*>(d.w1_lo);
     const __bf16* g2h = reinterpret_cast<const __bf16*>(d.w2_hi);
     const __bf16* g2l = reinterpret_cast<const __bf16*>(d.w2_lo);
+#ifdef GA_DC_PRIO
+    // two waves per SIMD: the second-dispatched half loses the vector-issue arbitration on every phase (priority, then age) and
+    // arrives last at every barrier; one static priority raise evens them out (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (NW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
+#endif
     const int nch = d.Hd / DC_CH;
     const int last = (nch - 1) * DC_CH;
     const int tap_o = (tid < 200 ? (tid >> 3) : 0) * d.Hd + 4 * c4;     // threads >= 200 load tap 0 again and drop it
@@ -255,7 +264,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
     wq.issue(g2h, g2l, d.Hd, 0, tid);
     taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o);
 
-    for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
+    for (int i = tid; i < plane_px * (DC_PS / 4); i += NTHR) reinterpret_cast<floatx4*>(P1)[i] = zero;
 
     bf16x8 xh[TMW][KS], xl[TMW][KS];
 #pragma unroll
@@ -440,11 +449,12 @@ __global__ void __launch_bounds__(256, 1) dec_cell_fwd_kernel(const ga_dec_cell_
 // dt3 . W2c^T | (d) -> P1 | (e) own strip *= SiLU'(t2c) | (f) depthwise^T, * P4 -> HBM; a barrier after each.  GEMM3 runs beside
 // SiLU'(t2c) in small scheduling regions.  (A two-GEMMs-beside-VALU software pipeline like the forward kernel's measured 7.75 + 5.29 ms
 // against 7.12 + 5.69 ms per 512 rows for this form: no gain for twice the bookkeeping.)
-template <int C, int TMW>
-__global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
-    constexpr int M = 128 * TMW, KS = C / 16, SW = 4 * TMW;
+template <int C, int TMW, int NW>
+__global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_bwd_kernel(const ga_dec_cell_desc d, const dc_geom gm) {
+    constexpr int NTHR = 64 * NW;
+    constexpr int M = 32 * TMW * NW, KS = C / 16, SW = M / (NTHR / 8);
     constexpr int BH = TMW == 2 ? 2 : 1, BW = SW / BH;
-    using WA = w_chunk<C, true>;
+    using WA = w_chunk<C, true, NTHR>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* wS = smem;                                                   // [25][32] forward taps of the chunk
     float* wT = smem + 25 * DC_CH;                                      // [25][32] flipped taps
@@ -475,7 +485,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_bwd_kernel(const ga_dec_cell_
         tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
     }
 
-    for (int i = tid; i < plane_px * (DC_PS / 4); i += 256) reinterpret_cast<floatx4*>(P1)[i] = zero;
+    for (int i = tid; i < plane_px * (DC_PS / 4); i += NTHR) reinterpret_cast<floatx4*>(P1)[i] = zero;
 
     bf16x8 xh[TMW][KS], xl[TMW][KS], gh[TMW][KS], gl[TMW][KS];
 #pragma unroll
@@ -653,19 +663,19 @@ static size_t dc_lds_bytes(int C, int M, int H, int W, bool bwd) {
                : (size_t)(25 * DC_CH + plane_px * DC_PS) * 4 + (size_t)2 * M * DC_LDB * 2 + rows32 + cols32;
 }
 
-template <int C, int TMW>
+template <int C, int TMW, int NW>
 static int launch_dec_cell(const ga_dec_cell_desc& d, const dc_geom& gm, hipStream_t stream) {
-    constexpr int M = 128 * TMW;
+    constexpr int M = 32 * TMW * NW;
     const size_t lds = dc_lds_bytes(C, M, d.H, d.W, d.backward != 0);
     const dim3 grid((unsigned)((size_t)d.N * d.H * d.W / M));
     if (d.backward) {
         static dyn_lds_cache attr;
-        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_bwd_kernel<C, TMW>), lds)) return GA_E_LAUNCH;
-        hipLaunchKernelGGL((dec_cell_bwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
+        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_bwd_kernel<C, TMW, NW>), lds)) return GA_E_LAUNCH;
+        hipLaunchKernelGGL((dec_cell_bwd_kernel<C, TMW, NW>), grid, dim3(64 * NW), lds, stream, d, gm);
     } else {
         static dyn_lds_cache attr;
-        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_fwd_kernel<C, TMW>), lds)) return GA_E_LAUNCH;
-        hipLaunchKernelGGL((dec_cell_fwd_kernel<C, TMW>), grid, dim3(256), lds, stream, d, gm);
+        if (!ensure_dyn_lds(attr, reinterpret_cast<const void*>(&dec_cell_fwd_kernel<C, TMW, NW>), lds)) return GA_E_LAUNCH;
+        hipLaunchKernelGGL((dec_cell_fwd_kernel<C, TMW, NW>), grid, dim3(64 * NW), lds, stream, d, gm);
     }
     return check_launch();
 }
@@ -685,7 +695,7 @@ extern "C" int ga_dec_cell_supported(int N, int H, int W, int C, int Hd) {
     if (log2_exact(W) < 0 || log2_exact(H) < 0) return 0;
     const long HW = (long)H * W;
     if (HW > M || M % HW || W % (M / 32)) return 0;          // whole images per workgroup, strips inside one image row
-    if (C == 128 && H % 2) return 0;                         // the 128-channel kernel's depthwise outputs are 2 x 4 blocks
+    if (C == 128 && H % 2) return 0;                         // the 128-channel kernel's depthwise outputs are 2 x 4 blocks (4-wave form)
     if (((long)N * HW) % M) return 0;
     return dc_lds_bytes(C, M, H, W, true) <= DC_LDS_MAX && dc_lds_bytes(C, M, H, W, false) <= DC_LDS_MAX;
 }
@@ -704,7 +714,7 @@ extern "C" int ga_dec_cell(const ga_dec_cell_desc* dp, void* stream_) {
     dc_geom gm;
     gm.W = d.W; gm.HW = d.H * d.W; gm.lw = log2_exact(d.W); gm.lhw = log2_exact(gm.HW); gm.PW = d.W + 4; gm.PH = d.H + 4;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    if (d.C == 128) return launch_dec_cell<128, 2>(d, gm, stream);
-    if (d.C == 256) return launch_dec_cell<256, 1>(d, gm, stream);
+    if (d.C == 128) return d.variant == 1 ? launch_dec_cell<128, 1, 8>(d, gm, stream) : launch_dec_cell<128, 2, 4>(d, gm, stream);
+    if (d.C == 256) return launch_dec_cell<256, 1, 4>(d, gm, stream);
     return GA_E_UNSUPPORTED;
 }

@@ -91,6 +91,7 @@ class NvaeBuilder:
                 (h1, l1), (h2, l2) = self.store.split(wts['w1']), self.store.split(wts['w2_bwd' if backward else 'w2'])
                 f.w1_hi, f.w1_lo, f.w2_hi, f.w2_lo = _ptr(h1), _ptr(l1), _ptr(h2), _ptr(l2)
             f.N, f.H, f.W, f.C, f.Hd, f.backward = n, H, W, x.c, hid_c, backward
+            f.variant = self.dec_cell_variant if x.c == 128 else 0
             return f
 
         if fused:

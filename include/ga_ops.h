@@ -382,7 +382,8 @@ typedef struct ga_dec_cell_desc {
     int N, H, W, C, Hd; int backward;
     int act_rep;              /* backward, > 1: N counts cotangent rows (dout, pro_scale, pro_shift, y); x has N/act_rep rows, cotangent
                                  row n recomputes from x row n / act_rep */
-    int _reserved;
+    int variant;              /* 0: four waves per workgroup (one per SIMD); 1: eight waves (two per SIMD, half the rows each), built
+                                 for C = 128 — same arithmetic, same results */
 } ga_dec_cell_desc;
 int ga_dec_cell(const ga_dec_cell_desc* d, void* stream);
 int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_dec_cell takes the shape */

@@ -66,6 +66,12 @@ print(f'conv N{N} H{H} {Cin}->{Cout} k{K} tile{tile} splits{splits} aff{aff} act
 print(f'grid span (first start -> last end): {(t[:, 4].max() - t0)} clk;  starts spread over {(t[:, 0].max() - t0)} clk')
 for i, nm in enumerate(('setup', 'first tile', 'K loop', 'epilogue')):
     print(f'  {nm:10s} mean {ph[:, i].mean():9.0f}  min {ph[:, i].min():8d}  max {ph[:, i].max():8d} clk')
+if tile >= 5:
+    nst = K * K * -(-Cin // 32) // splits
+    inner = t[:, 5:8].astype(np.float64)
+    print(f'  K-loop anatomy, wave 0, clocks per step ({nst} steps): MFMA part {inner[:, 0].mean() / nst:7.0f}  '
+          f'patch staging at chunk ends {inner[:, 1].mean() / nst:7.0f}  step barrier {inner[:, 2].mean() / nst:7.0f}   '
+          f'(MFMA floor alone on the SIMD: {24 * 32 if tile == 5 else 0} clk per step at 128x128)')
 # each XCD has its own counter; workgroup i is dispatched to XCD i % 8 -> starts relative to the XCD's first workgroup
 rel = np.zeros(nwg, dtype=np.int64)
 for xcd in range(8):

@@ -49,6 +49,7 @@ for backward in (0, 1):
     else:
         d.w2_hi, d.w2_lo, d.y = w2h.data_ptr(), w2l.data_ptr(), y.data_ptr()
     d.N, d.H, d.W, d.C, d.Hd, d.backward = N, H, H, Cc, Hd, backward
+    d.variant = int(os.environ.get('GA_DEC_CELL_VARIANT', '0'))
     for _ in range(3):
         L.run(d)
     torch.cuda.synchronize()
