@@ -43,7 +43,7 @@ class ConvDesc(C.Structure):
                 ('pro_act', i32), ('pro_per_row', i32), ('dact_act', i32), ('addend_bcast_n', i32), ('tile', i32),
                 ('splits', i32), ('ws', fp), ('ws_floats', C.c_long),
                 ('x_bytes', C.c_uint), ('x2_bytes', C.c_uint), ('w_bytes', C.c_uint), ('dact_rep', i32),
-                ('w_hi', fp), ('w_lo', fp), ('addend_rep', i32), ('flags', i32)]
+                ('w_hi', fp), ('w_lo', fp), ('addend_rep', i32), ('flags', i32), ('w_frag', fp)]
 
 
 class DwDesc(C.Structure):

@@ -327,6 +327,251 @@ static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 gri
                        nkc, vec_out, g);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_halo3_bd — the same convolution with the WEIGHT FRAGMENTS READ STRAIGHT FROM GLOBAL MEMORY (tile code 8).
+//
+// Anatomy of the kernel above at 512 rows x 16 x 16 x 128 (tools/conv_trace.py, trace build; clocks per tap step of one
+// workgroup, two workgroups per CU): MFMA part 1705 (two waves' 2 x 768 on the shared matrix pipe + the weight tile's register ->
+// LDS writes), patch staging at the chunk boundaries 250, step barrier 264.  A third of a step goes to handing the next weight
+// tile from registers through LDS to the waves — one barrier per 24 MFMAs.  Here a wave owns all 128 pixels of the tile and a
+// quarter of the output channels (waves 1 x 4 instead of 2 x 2): its B fragments are then nobody else's, so they need no LDS and no
+// barrier.  They are loaded a whole step ahead with fully coalesced 1-KB wave loads from a copy of the weights laid out in
+// fragment order at load time (`w_frag`: [N tile][chunk][tap][wave][k step][hi | lo][lane][8 bf16], written by the host once),
+// and the patch is double-buffered where it fits: ONE barrier per 32-channel chunk (9 taps, 216 MFMAs per wave) instead of nine.
+// Same operand split, k order and accumulation order as conv_halo3_kernel: bitwise the same results.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int AFF, int ACT, int RPMAX>
+__global__ void __launch_bounds__(256, 2)
+conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C, const int nkc, const int vec_out,
+                     const halo_geom g, const int dbuf) {
+    constexpr int WM = 1, WN = 4, TM = 4, TN = 1, BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int plane = g.NI * g.IS;                           // bf16 elements of one patch plane (hi or lo)
+    __bf16* Pbase = reinterpret_cast<__bf16*>(smem);         // buffer b: hi at b * 2 * plane, lo behind it
+    GA_HSTAMP(0)
+
+    int bid;
+    {
+        const int nb = gridDim.x, orig = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = orig & 7, k = orig >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = (bid / tilesN) * BM;
+    const int nt = bid % tilesN, n0 = nt * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave;
+    const int c4 = tid & 7;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    constexpr int INV = 0x7fffffff;
+    const int HoWo = d.Ho * d.Wo;
+    const int n_first = fd_div(m0, g.fd_howo);
+    const int y0 = HoWo > BM ? fd_div(m0 - n_first * HoWo, g.fd_wo) : 0;
+    const int x0 = g.wide ? m0 - n_first * HoWo - y0 * d.Wo : 0;
+    const int rp = (g.P * 8 + 255) >> 8;
+
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
+
+    int pbase[RPMAX], plds[RPMAX];
+    int prow[AFF == 2 ? RPMAX : 1];
+    unsigned okbits = 0;
+#pragma unroll
+    for (int j = 0; j < RPMAX; ++j) {
+        const int pp = (tid + 256 * j) >> 3;
+        int off = INV;
+        plds[j] = -1;
+        if (AFF == 2) prow[j] = 0;
+        if (j < rp && pp < g.P) {
+            const int img = fd_div(pp, g.fd_phpw);
+            const int rem = pp - img * g.PH * g.PW;
+            const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
+            plds[j] = img * g.IS + py * g.RS + px * LDH + 4 * c4;
+            const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
+            if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
+                off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
+                okbits |= 1u << j;
+                if (AFF == 2) prow[j] = n * C + 4 * c4;
+            }
+        }
+        pbase[j] = off;
+    }
+    int fragA[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int o = i * 32 + lrow;
+        const int img = fd_div(o, g.fd_thwo);
+        const int rem = o - img * g.TH * g.TW;
+        const int y = fd_div(rem, g.fd_tw), x = rem - y * g.TW;
+        fragA[i] = img * g.IS + y * g.RS + x * LDH + 8 * lh;
+    }
+
+    floatx4 rpat[RPMAX], rs = {1.f, 1.f, 1.f, 1.f}, rt = {0.f, 0.f, 0.f, 0.f};
+    auto issue_patch = [&](const int chunk) __attribute__((always_inline)) {
+        const int soff = chunk * HK * 4;
+#pragma unroll
+        for (int j = 0; j < RPMAX; ++j)
+            if (j < rp) rpat[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, pbase[j], soff, 0));
+        if (AFF == 1) {
+            rs = *reinterpret_cast<const floatx4*>(d.pro_scale + chunk * HK + 4 * c4);
+            rt = *reinterpret_cast<const floatx4*>(d.pro_shift + chunk * HK + 4 * c4);
+        }
+    };
+    auto finish_patch = [&](const int chunk, const int buf) __attribute__((always_inline)) {
+        const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
+        __bf16* Ph = Pbase + buf * 2 * plane;
+        __bf16* Pl = Ph + plane;
+#pragma unroll
+        for (int j = 0; j < RPMAX; ++j) {
+            if (j < rp) {
+                floatx4 v = rpat[j];
+                if (AFF == 1) {
+                    if (d.flags & GA_CONV_PRO_PRELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * rs[e];
+                    } else {
+                        v = v * rs + rt;
+                    }
+                }
+                if (AFF == 2) {
+                    const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow[j] + chunk * HK);
+                    const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow[j] + chunk * HK);
+                    v = v * ps + pt;
+                }
+                if (ACT == GA_ACT_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * fast_sigmoid(v[e]);
+                } else if (ACT == GA_ACT_ELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : __expf(v[e]) - 1.f;
+                } else if (ACT == GA_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (ACT == GA_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                }
+                if (AFF != 0) v = (okbits >> j) & 1u ? v : zero;
+                const bf16x4 hi = __builtin_convertvector(v, bf16x4);
+                const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
+                if (plds[j] >= 0) {
+                    *reinterpret_cast<bf16x4*>(Ph + plds[j]) = hi;
+                    *reinterpret_cast<bf16x4*>(Pl + plds[j]) = lo;
+                }
+            }
+        }
+    };
+
+    // weight fragments of (chunk, tap): 4 x 16 bytes per lane (k step 0 / 1 x hi / lo), lane-linear 1-KB pieces
+    const uintx4* wf = reinterpret_cast<const uintx4*>(d.w_frag) + ((size_t)nt * nkc * 9 * 4 + wn) * 4 * 64 + lane;
+    uintx4 bcur[4], bnxt[4];
+    auto load_B = [&](uintx4 (&b)[4], const int chunk, const int tap) __attribute__((always_inline)) {
+        const uintx4* p = wf + (size_t)(chunk * 9 + tap) * (4 * 4 * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[q] = p[q * 64];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    // A fragments of group (tap, k step) = 8 ds_read_b128 feeding 12 MFMAs; two register sets: the reads of group g + 1 are issued
+    // BEFORE the MFMAs of group g (the waits the compiler inserts are then counted ones: lgkmcnt(8) instead of a drain), so that
+    // a wave's instruction stream is MFMAs back to back with its operand reads riding in the gaps
+    bf16x8 ahs[2][TM], als[2][TM];
+    auto load_A = [&](const int set, const int buf, const int off) __attribute__((always_inline)) {
+        const __bf16* Ph = Pbase + buf * 2 * plane;
+        const __bf16* Pl = Ph + plane;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            ahs[set][i] = *reinterpret_cast<const bf16x8*>(Ph + fragA[i] + off);
+            als[set][i] = *reinterpret_cast<const bf16x8*>(Pl + fragA[i] + off);
+        }
+    };
+    auto mma_group = [&](const int set, const uintx4 bh4, const uintx4 bl4) __attribute__((always_inline)) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh4), bl = __builtin_bit_cast(bf16x8, bl4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(als[set][i], bh, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bl, acc[i][0], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bh, acc[i][0], 0, 0, 0);
+        }
+    };
+
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int cper = (nkc + splits - 1) / splits;
+    const int cb = split * cper, ce = min(nkc, cb + cper);
+
+    GA_HSTAMP(1)
+    if (cb < ce) {
+        issue_patch(cb);
+        load_B(bcur, cb, 0);
+        finish_patch(cb, 0);
+        if (cb + 1 < ce) issue_patch(cb + 1);
+    }
+    __syncthreads();
+    GA_HSTAMP(2)
+    int buf = 0;
+    const int rowskip = g.RS - 3 * LDH;
+    for (int chunk = cb; chunk < ce; ++chunk) {
+        load_A(0, buf, 0);
+#pragma unroll
+        for (int gi = 0; gi < 18; ++gi) {
+            const int tap = gi >> 1, ks = gi & 1;
+            if (ks == 0) {
+                // the next tap's weight fragments fly during this tap's 24 MFMAs (the last tap of the last chunk re-reads its own)
+                const int ntap = tap == 8 ? 0 : tap + 1;
+                const int nchunk = tap == 8 ? min(chunk + 1, ce - 1) : chunk;
+                load_B(bnxt, nchunk, ntap);
+            }
+            if (gi + 1 < 18) {
+                const int nt2 = (gi + 1) >> 1;
+                const int noff = nt2 * LDH + (nt2 / 3) * rowskip + ((gi + 1) & 1) * 16;
+                load_A((gi + 1) & 1, buf, noff);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // (the global loads, when this group has them)
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // next group's 8 fragment reads first ...
+            mma_group(gi & 1, bcur[2 * ks], bcur[2 * ks + 1]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // ... then this group's 12 MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+            if (dbuf && gi == 9 && chunk + 1 < ce) {        // the next chunk's patch into the other buffer, behind the MFMAs
+                finish_patch(chunk + 1, buf ^ 1);
+                if (chunk + 2 < ce) issue_patch(chunk + 2);
+            }
+            if (ks == 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
+            }
+        }
+        if (chunk + 1 < ce) {
+            if (dbuf) {
+                __syncthreads();                            // the other buffer is complete, nobody reads this one any more
+                buf ^= 1;
+            } else {
+                __syncthreads();                            // every wave has read the patch
+                finish_patch(chunk + 1, 0);
+                if (chunk + 2 < ce) issue_patch(chunk + 2);
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+    GA_HSTAMP(3)
+    conv_epilogue<WM, WN, TM, TN>(d, acc, smem, m0, n0, M, vec_out, splits, split);
+    GA_HSTAMP(4)
+}
+
+template <int AFF, int ACT, int RP>
+static void launch_halo_bd_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int nkc, int vec_out,
+                                const halo_geom& g, int dbuf) {
+    static dyn_lds_cache attr;
+    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_halo3_bd_kernel<AFF, ACT, RP>), lds);
+    hipLaunchKernelGGL((conv_halo3_bd_kernel<AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, nkc, vec_out, g, dbuf);
+}
+
 static inline int halo_mode(const ga_conv_desc& d) {
     return ((d.pro_scale ? (d.pro_per_row ? 2 : 1) : 0) << 4) | d.pro_act;
 }
@@ -346,14 +591,8 @@ int conv_halo3_supports(const ga_conv_desc& d) {
     }
 }
 
-template <int WM, int WN, int TM, int TN>
-static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    const int M = d.N * d.Ho * d.Wo;
-    const int Ktot = 9 * d.C1;
-    const int nkc = d.C1 / HK;
+static int halo_geometry(const ga_conv_desc& d, const int BM, halo_geom& g) {
     const int HoWo = d.Ho * d.Wo;
-    halo_geom g;
     g.wide = d.Wo >= BM ? 1 : 0;
     g.TW = g.wide ? BM : d.Wo;
     g.TH = g.wide ? 1 : (HoWo >= BM ? BM / d.Wo : d.Ho);
@@ -373,6 +612,17 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
     g.fd_pw = make_fastdiv(g.PW);
     g.fd_thwo = make_fastdiv(g.TH * g.TW);
     g.fd_tw = make_fastdiv(g.TW);
+    return GA_OK;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const int M = d.N * d.Ho * d.Wo;
+    const int Ktot = 9 * d.C1;
+    const int nkc = d.C1 / HK;
+    halo_geom g;
+    { const int rc = halo_geometry(d, BM, g); if (rc != GA_OK) return rc; }
     if (splits > nkc) return GA_E_UNSUPPORTED;
     const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
     size_t lds = ((size_t)2 * g.NI * g.IS + (size_t)2 * 2 * BN * LDH) * 2;
@@ -403,9 +653,44 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
     return check_launch();
 }
 
-// tile codes 5 (128 x 128), 6 (128 x 64) and 7 (128 x 32) of ga_conv_desc.tile; called by ga_conv2d after validation
+static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
+    constexpr int BM = 128, BN = 128;
+    if (!d.w_frag || !aligned16(d.w_frag)) return GA_E_UNSUPPORTED;
+    const int M = d.N * d.Ho * d.Wo;
+    const int nkc = d.C1 / HK;
+    halo_geom g;
+    { const int rc = halo_geometry(d, BM, g); if (rc != GA_OK) return rc; }
+    if (splits > nkc) return GA_E_UNSUPPORTED;
+    const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
+    const size_t patch = (size_t)2 * g.NI * g.IS * 2;                   // hi + lo planes of one buffer, bytes
+    const int dbuf = 2 * patch <= 80 * 1024 ? 1 : 0;                    // two buffers when two workgroups per CU still fit
+    size_t lds = (dbuf ? 2 : 1) * patch;
+    if (lds > 160 * 1024) return GA_E_UNSUPPORTED;
+    const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
+    if (lds_c > lds) lds = lds_c;
+    const dim3 grid(tilesM * tilesN, splits);
+#define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf)
+    if (g.P > 9 * 32) return GA_E_UNSUPPORTED;                          // row-segment tiles of wide images: the LDS-staged kernel
+    switch (halo_mode(d)) {
+        case 0x00: GA_HBD(0, GA_ACT_NONE); break;
+        case 0x01: GA_HBD(0, GA_ACT_SILU); break;
+        case 0x02: GA_HBD(0, GA_ACT_ELU); break;
+        case 0x03: GA_HBD(0, GA_ACT_RELU); break;
+        case 0x04: GA_HBD(0, GA_ACT_LRELU); break;
+        case 0x10: GA_HBD(1, GA_ACT_NONE); break;
+        case 0x11: GA_HBD(1, GA_ACT_SILU); break;
+        case 0x20: GA_HBD(2, GA_ACT_NONE); break;
+        default: return GA_E_UNSUPPORTED;
+    }
+#undef GA_HBD
+    return check_launch();
+}
+
+// tile codes 5 (128 x 128), 6 (128 x 64) and 7 (128 x 32) of ga_conv_desc.tile, 8 = 128 x 128 with the weight fragments read from
+// global memory (needs w_frag); called by ga_conv2d after validation
 int conv_halo3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
     switch (tile) {
+        case 8: return launch_halo_bd(d, stream, vec_out, splits);
         case 5: return launch_halo<2, 2, 2, 2>(d, stream, vec_out, splits);
         case 6: return launch_halo<4, 1, 1, 2>(d, stream, vec_out, splits);
         case 7: return launch_halo<4, 1, 1, 1>(d, stream, vec_out, splits);

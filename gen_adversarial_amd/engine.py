@@ -165,6 +165,10 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         if self.precision == 'bf16x3' and not self.dry_run and not precise:
             hi, lo = self.store.split(w)
             d.w_hi, d.w_lo = _ptr(hi), _ptr(lo)
+            kh, kw = (KH or K), (KW or K)
+            if (kh, kw, sn, sd, pad) == (3, 3, 1, 1, 1) and x2 is None and (cin or x.shape[3]) % 32 == 0 and 128 % x.shape[2] == 0 \
+                    and w.dim() == 2 and w.shape[1] == 9 * (cin or x.shape[3]):
+                d.w_frag = _ptr(self.store.frag3(w))        # tile 8: B fragments straight from global memory
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
         No, Ho, Wo, Cy = y.shape
         d.y, d.ldy = _ptr(y), (ldy or Cy)
@@ -443,8 +447,10 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             best = None
             modes = (1, 0) if d.w_hi else (0,)
             halo = (5, 6, 7) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
+            if halo and d.w_frag:
+                halo = halo + (8,)
             for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + (halo if m_ else ())]:
-                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32)}[tile]
+                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32), 8: (128, 128)}[tile]
                 if bn >= 2 * max(32, d.Cout) and tile not in (4, 7):
                     continue
                 blocks = -(-M // bm) * -(-d.Cout // bn)

@@ -56,6 +56,26 @@ class WeightStore:
             self.bytes += 4 * w.numel()
         return self.splits[k][0], self.splits[k][1]
 
+    def frag3(self, w: torch.Tensor) -> torch.Tensor:
+        """the split weights of a 3x3 conv ([Cout][9 * C] fp32, C % 32 == 0) in the MFMA-fragment order of ga_conv_desc.w_frag
+        (bf16 [ceil(Cout/128)][C/32][9][4 waves][2 k steps][hi | lo][64 lanes][8]); made once per tensor"""
+        k = ('frag3', w.data_ptr())
+        if k not in self.splits:
+            hi, lo = self.split(w)
+            cout, kk = w.shape
+            c = kk // 9
+            nt, nkc = (cout + 127) // 128, c // 32
+
+            def arr(t):
+                tp = torch.zeros(nt * 128, kk, dtype=torch.bfloat16, device=t.device)
+                tp[:cout] = t
+                # [nt, wave, row, tap, chunk, k step, lane half, e] -> [nt, chunk, tap, wave, k step, lane half, row, e]
+                return tp.view(nt, 4, 32, 9, nkc, 2, 2, 8).permute(0, 4, 3, 1, 5, 6, 2, 7)
+            f = torch.stack([arr(hi), arr(lo)], dim=5).contiguous()          # hi | lo between the k step and the lane
+            self.splits[k] = (f, w)
+            self.bytes += 2 * f.numel()
+        return self.splits[k][0]
+
     def get(self, key: str, fn):
         if key not in self.cache:
             d = {k: v.to(self.device, dtype=torch.float32).contiguous() for k, v in fn().items()}

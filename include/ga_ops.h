@@ -84,7 +84,8 @@ typedef struct ga_conv_desc {
     int tile;                              /* 0 = auto; 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32 (M x N);
                                               5 = 128x128, 6 = 128x64, 7 = 128x32 on the halo-staged 3x3 kernel (3x3, stride 1,
                                               pad 1, C1 % 32 == 0, 128 % Wo == 0 or Wo % 128 == 0, w_hi/w_lo given;
-                                              GA_E_UNSUPPORTED otherwise) */
+                                              GA_E_UNSUPPORTED otherwise); 8 = 128x128 on the same kernel with the weight
+                                              fragments read from global memory (w_frag given, 128 % Wo == 0) */
     int splits;                            /* split-K factor (<=1: none); needs ws */
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
     long ws_floats;
@@ -97,6 +98,11 @@ typedef struct ga_conv_desc {
     int addend_rep;                        /* > 1: addend has N/addend_rep rows, row n reads addend row n / addend_rep
                                               (EoT replicas sharing one encoder feature map) */
     int flags;                             /* GA_CONV_* bits below */
+    const void* w_frag;                    /* optional, tile 8 only: the split weights of a 3x3 conv in MFMA-fragment order, bf16
+                                              [ceil(Cout/128)][C1/32][9 taps][4 waves][2 k steps][hi | lo][64 lanes][8]: element e of
+                                              lane l = W[128 t + 32 wave + (l & 31)][tap * C1 + 32 chunk + 16 kstep + 8 (l >> 5) + e]
+                                              (rows >= Cout zero).  The halo kernel then reads its B fragments from global memory:
+                                              no weight staging through LDS, one barrier per 32-channel chunk */
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 

@@ -37,6 +37,11 @@ if aff:
 hi = w.to(torch.bfloat16)
 lo = (w - hi.float()).to(torch.bfloat16)
 d.w_hi, d.w_lo = hi.data_ptr(), lo.data_ptr()
+if tile == 8:
+    from gen_adversarial_amd.engine_core import WeightStore
+    _store = WeightStore('cuda')
+    _frag = _store.frag3(w)
+    d.w_frag = _frag.data_ptr()
 for _ in range(3):
     L.run(d)
 torch.cuda.synchronize()
@@ -50,7 +55,7 @@ e1.synchronize()
 us = e0.elapsed_time(e1) / reps * 1e3
 L.run(d)
 torch.cuda.synchronize()
-bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64)}[tile]
+bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 8: (128, 128)}[tile]
 M = N * H * H
 nwg = min(8192, -(-M // bm) * -(-Cout // bn))
 buf = np.zeros(8 * 8192, dtype=np.uint64)
@@ -66,7 +71,7 @@ print(f'conv N{N} H{H} {Cin}->{Cout} k{K} tile{tile} splits{splits} aff{aff} act
 print(f'grid span (first start -> last end): {(t[:, 4].max() - t0)} clk;  starts spread over {(t[:, 0].max() - t0)} clk')
 for i, nm in enumerate(('setup', 'first tile', 'K loop', 'epilogue')):
     print(f'  {nm:10s} mean {ph[:, i].mean():9.0f}  min {ph[:, i].min():8d}  max {ph[:, i].max():8d} clk')
-if tile >= 5:
+if tile in (5, 6, 7):
     nst = K * K * -(-Cin // 32) // splits
     inner = t[:, 5:8].astype(np.float64)
     print(f'  K-loop anatomy, wave 0, clocks per step ({nst} steps): MFMA part {inner[:, 0].mean() / nst:7.0f}  '
