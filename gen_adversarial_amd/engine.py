@@ -45,7 +45,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
     # (the reference protocol of one image x EoT 32 would pay 10 ms of a 21 ms step).  GA_FUSE_DEC_CELL=force: always (tests).
     fuse_min_workgroups = 0 if os.environ.get('GA_FUSE_DEC_CELL') == 'force' else 160
     # ga_dec_cell variant for the 128-channel cells: 0 = four waves per workgroup, 1 = eight (two per SIMD); same results
-    dec_cell_variant = int(os.environ.get('GA_DEC_CELL_VARIANT', '0'))
+    dec_cell_variant = int(os.environ.get('GA_DEC_CELL_VARIANT', '1'))
 
     def __init__(self, nvae_sd, nvae_cfg: dict, resolution, vgg_sd, vgg_spec: VggSpec, rows: int, rep: int,
                  alphas: Sequence[float], temperature: float = 0.6, noise_eps: float = 0.0,

@@ -83,6 +83,12 @@ def test_dec_cell_forward_and_backward(N, H, Cc, Hd):
     diff = (y - u3).abs().max().item()
     print(f'fused vs unfused forward: max |diff| {diff:.3e} of {scale:.3e}, bitwise equal: {torch.equal(y, u3)}')
     assert diff <= 2e-6 * scale
+    if Cc == 128:                # the eight-wave form of the 128-channel cell: same sums in the same order
+        y1 = torch.full((N, H, H, Cc), float('nan'), device=DEV)
+        d.y, d.variant = y1.data_ptr(), 1
+        L.run(d)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y1), 'ga_dec_cell variant 1 (forward) differs from variant 0'
 
     # ---- backward: d loss / d t1 for d loss / d t3 = dout * ps[n] + pb[n]
     dout = g(N, Cc, H, H, seed=21)
@@ -101,6 +107,12 @@ def test_dec_cell_forward_and_backward(N, H, Cc, Hd):
     L.run(b)
     torch.cuda.synchronize()
     close(nchw(dt1), gt1, 2e-4, 'fused backward vs autograd')
+    if Cc == 128:
+        dt1b = torch.full((N, H, H, Hd), float('nan'), device=DEV)
+        b.y, b.variant = dt1b.data_ptr(), 1
+        L.run(b)
+        torch.cuda.synchronize()
+        assert torch.equal(dt1, dt1b), 'ga_dec_cell variant 1 (backward) differs from variant 0'
 
     # unfused: 1x1 transpose with the per-row prologue and silu'(t2) epilogue, then the depthwise transpose with silu'(t1)
     v2 = torch.empty(N, H, H, Hd, device=DEV)

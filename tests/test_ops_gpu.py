@@ -18,7 +18,7 @@ if not torch.cuda.is_available():
 from gen_adversarial_amd import _lib as L   # noqa: E402
 
 DEV = 'cuda:0'
-ACTS = {0: lambda u: u, 1: F.silu, 2: F.elu, 3: F.relu}
+ACTS = {0: lambda u: u, 1: F.silu, 2: F.elu, 3: F.relu, 4: F.leaky_relu}
 
 
 def nhwc(t):   # NCHW cpu -> NHWC gpu
@@ -247,6 +247,58 @@ def test_conv_halo3(N, H, W, Cin, Cout, act, affine, tile, splits):
         else:       # the halo kernel needs 32-channel chunks: the request is refused, not silently rerouted
             with pytest.raises(L.GaError):
                 run_conv(nhwc(cot), wb, dx, 3, pad=1, tile=tile, **kb)
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,act,mode,splits,dact', [
+    (5, 16, 16, 128, 128, 1, 'affine', 1, 0),     # the 16^2 x 128 decoder / encoder shape, ragged last tiles
+    (9, 8, 8, 64, 200, 0, 'none', 2, 1),          # two images per tile, Cout not a 128 multiple (zero-padded fragments), two K splits
+    (17, 4, 4, 96, 128, 2, 'none', 3, 0),         # eight 4x4 images per tile + tail, three K splits, ELU
+    (2, 32, 32, 32, 64, 3, 'none', 1, 1),         # 4 image rows per tile, one channel chunk, ReLU
+    (3, 8, 8, 64, 128, 0, 'per_row', 1, 0),       # the SE-gate prologue of conv2^T
+    (1, 2, 64, 32, 32, 4, 'none', 1, 0),          # 64-wide rows, LeakyReLU
+])
+def test_conv_halo3_fragment_weights(N, H, W, Cin, Cout, act, mode, splits, dact):
+    """tile 8 (weights read as ready MFMA fragments from ga_conv_desc.w_frag, engine_core.WeightStore.frag3) does the same
+    arithmetic in the same order as tile 5: the two outputs are equal bit for bit, and both meet the split-bf16 bar against
+    torch.  Without w_frag the request is refused."""
+    from gen_adversarial_amd.engine_core import WeightStore
+    x = g(N, Cin, H, W, seed=1)
+    w = g(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
+    b = g(Cout, seed=3)
+    u = x
+    kw = dict(bias=b.to(DEV), pro_act=act, splits=splits)
+    if mode == 'affine':
+        sc, sh = torch.rand(Cin, generator=torch.Generator().manual_seed(4)) + 0.5, g(Cin, seed=5, scale=0.3)
+        u = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV))
+    elif mode == 'per_row':
+        sc, sh = torch.rand(N, Cin, generator=torch.Generator().manual_seed(4)) + 0.5, g(N, Cin, seed=5, scale=0.3)
+        u = x * sc.view(N, Cin, 1, 1) + sh.view(N, Cin, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV), pro_per_row=1)
+    ref = F.conv2d(ACTS[act](u), w, b, padding=1)
+    ws_store = WeightStore(torch.device(DEV))
+    wf = fwd_w(w)
+    hi, lo = ws_store.split(wf)
+    frag = ws_store.frag3(wf)
+    kw.update(w_hi=hi, w_lo=lo)
+    if dact:                     # the act' epilogue of a backward-to-input launch
+        dx = g(N, Cout, H, W, seed=7)
+        kw.update(dact_x=nhwc(dx), dact_act=1, lddact=Cout)
+        sg = torch.sigmoid(dx)
+        ref = ref * (sg * (1 + dx * (1 - sg)))
+    if splits > 1:
+        ws = torch.empty(splits * N * H * W * Cout, device=DEV)
+        kw.update(ws=ws, ws_floats=ws.numel())
+    xd = nhwc(x)
+    y5 = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+    y8 = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+    run_conv(xd, wf, y5, 3, pad=1, tile=5, **kw)
+    with pytest.raises(L.GaError):
+        run_conv(xd, wf, y8, 3, pad=1, tile=8, **kw)
+    assert torch.isnan(y8).all(), 'a refused launch wrote its output'
+    run_conv(xd, wf, y8, 3, pad=1, tile=8, w_frag=frag, **kw)
+    close(nchw(y8), ref, 2e-4, 'fragment-weight halo kernel vs torch')
+    assert torch.equal(y5, y8), f'tile 8 differs from tile 5: max {float((y5 - y8).abs().max()):.3e}'
 
 
 def test_conv_halo3_per_row_prologue():
