@@ -51,7 +51,7 @@ struct halo_geom {
     int TH, NI, PH, PW, P;      // rows per image in the tile, images per tile, patch rows / cols per image, patch pixels
     int TW, wide;               // tile width (= Wo, or 128 for a row segment of a wide image: wide = 1)
     int RS, IS;                 // row / image stride of a patch plane, in bf16 elements
-    fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo, fd_tw;
+    fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo, fd_tw, fd_is;
 };
 
 template <int WM, int WN, int TM, int TN, int AFF, int ACT, int RPMAX>
@@ -344,7 +344,7 @@ static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 gri
 template <int AFF, int ACT, int RPMAX>
 __global__ void __launch_bounds__(256, 2)
 conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C, const int nkc, const int vec_out,
-                     const halo_geom g, const int dbuf) {
+                     const halo_geom g, const int dbuf, const int tab_off) {
     constexpr int WM = 1, WN = 4, TM = 4, TN = 1, BM = 128, BN = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int plane = g.NI * g.IS;                           // bf16 elements of one patch plane (hi or lo)
@@ -374,29 +374,44 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
 
     const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, d.x_bytes, 0x00020000);
 
-    int pbase[RPMAX], plds[RPMAX];
-    int prow[AFF == 2 ? RPMAX : 1];
-    unsigned okbits = 0;
+    // patch slot j of this thread (patch pixel (tid + 256 j) >> 3, channel quad c4): its global byte offset (INV: padding or
+    // outside the batch) and its LDS element offset / 4 (0xffff: no such patch pixel) are per-thread constants that are needed
+    // once per 32-channel chunk; they live in LDS ([rp][256] ints, then [rp][256] shorts, behind the patch buffers) instead
+    // of 18 registers — two conflict-free LDS reads per slot and chunk, and the kernel fits its 256 registers without scratch
+    int* sl_g = reinterpret_cast<int*>(smem + tab_off);
+    unsigned short* sl_p = reinterpret_cast<unsigned short*>(sl_g + rp * 256);
 #pragma unroll
     for (int j = 0; j < RPMAX; ++j) {
-        const int pp = (tid + 256 * j) >> 3;
-        int off = INV;
-        plds[j] = -1;
-        if (AFF == 2) prow[j] = 0;
-        if (j < rp && pp < g.P) {
-            const int img = fd_div(pp, g.fd_phpw);
-            const int rem = pp - img * g.PH * g.PW;
-            const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
-            plds[j] = img * g.IS + py * g.RS + px * LDH + 4 * c4;
-            const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
-            if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
-                off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
-                okbits |= 1u << j;
-                if (AFF == 2) prow[j] = n * C + 4 * c4;
+        if (j < rp) {
+            const int pp = (tid + 256 * j) >> 3;
+            int off = INV, pl = 0xffff;
+            if (pp < g.P) {
+                const int img = fd_div(pp, g.fd_phpw);
+                const int rem = pp - img * g.PH * g.PW;
+                const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
+                pl = (img * g.IS + py * g.RS + px * LDH + 4 * c4) >> 2;
+                const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
+                if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
             }
+            sl_g[j * 256 + tid] = off;
+            sl_p[j * 256 + tid] = (unsigned short)pl;
         }
-        pbase[j] = off;
     }
+    // AFF != 0: the prologue's scale / shift table, staged once: [scale | shift][TI][C] floats behind the slot tables, TI = 1
+    // (per-channel affine, or the PReLU slopes) or the tile's NI images (per-(image, channel) affine)
+    float* ptab = reinterpret_cast<float*>(sl_p + rp * 256);
+    const int TI = AFF == 2 ? g.NI : 1;
+    if (AFF != 0) {
+        const int quads = TI * (C >> 2);
+        for (int q = tid; q < quads; q += 256) {
+            const int img = q / (C >> 2), cq = q - img * (C >> 2);
+            const size_t row = AFF == 2 ? (size_t)min(n_first + img, d.N - 1) * C : 0;
+            *reinterpret_cast<floatx4*>(ptab + img * C + 4 * cq) = *reinterpret_cast<const floatx4*>(d.pro_scale + row + 4 * cq);
+            *reinterpret_cast<floatx4*>(ptab + (TI + img) * C + 4 * cq) = *reinterpret_cast<const floatx4*>(d.pro_shift + row + 4 * cq);
+        }
+    }
+    // (the barrier in front of the K loop orders these writes before the first reads of other threads' entries; a thread's own
+    // slot entries are read by itself only)
     int fragA[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -407,25 +422,27 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
         fragA[i] = img * g.IS + y * g.RS + x * LDH + 8 * lh;
     }
 
-    floatx4 rpat[RPMAX], rs = {1.f, 1.f, 1.f, 1.f}, rt = {0.f, 0.f, 0.f, 0.f};
+    floatx4 rpat[RPMAX];
     auto issue_patch = [&](const int chunk) __attribute__((always_inline)) {
         const int soff = chunk * HK * 4;
 #pragma unroll
         for (int j = 0; j < RPMAX; ++j)
-            if (j < rp) rpat[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, pbase[j], soff, 0));
-        if (AFF == 1) {
-            rs = *reinterpret_cast<const floatx4*>(d.pro_scale + chunk * HK + 4 * c4);
-            rt = *reinterpret_cast<const floatx4*>(d.pro_shift + chunk * HK + 4 * c4);
-        }
+            if (j < rp) rpat[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, sl_g[j * 256 + tid], soff, 0));
     };
     auto finish_patch = [&](const int chunk, const int buf) __attribute__((always_inline)) {
         const floatx4 zero = {0.f, 0.f, 0.f, 0.f};
         __bf16* Ph = Pbase + buf * 2 * plane;
         __bf16* Pl = Ph + plane;
+        floatx4 rs = {1.f, 1.f, 1.f, 1.f}, rt = {0.f, 0.f, 0.f, 0.f};
+        if (AFF == 1) {
+            rs = *reinterpret_cast<const floatx4*>(ptab + chunk * HK + 4 * c4);
+            rt = *reinterpret_cast<const floatx4*>(ptab + C + chunk * HK + 4 * c4);
+        }
 #pragma unroll
         for (int j = 0; j < RPMAX; ++j) {
             if (j < rp) {
                 floatx4 v = rpat[j];
+                const int pl = sl_p[j * 256 + tid];
                 if (AFF == 1) {
                     if (d.flags & GA_CONV_PRO_PRELU) {
 #pragma unroll
@@ -435,9 +452,9 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
                     }
                 }
                 if (AFF == 2) {
-                    const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow[j] + chunk * HK);
-                    const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow[j] + chunk * HK);
-                    v = v * ps + pt;
+                    const int img = fd_div(4 * pl, g.fd_is);
+                    const float* tp = ptab + img * C + chunk * HK + 4 * c4;
+                    v = v * *reinterpret_cast<const floatx4*>(tp) + *reinterpret_cast<const floatx4*>(tp + TI * C);
                 }
                 if (ACT == GA_ACT_SILU) {
 #pragma unroll
@@ -452,12 +469,12 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
-                if (AFF != 0) v = (okbits >> j) & 1u ? v : zero;
+                if (AFF != 0) v = sl_g[j * 256 + tid] != INV ? v : zero;        // only a shift un-zeroes the padding
                 const bf16x4 hi = __builtin_convertvector(v, bf16x4);
                 const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
-                if (plds[j] >= 0) {
-                    *reinterpret_cast<bf16x4*>(Ph + plds[j]) = hi;
-                    *reinterpret_cast<bf16x4*>(Pl + plds[j]) = lo;
+                if (pl != 0xffff) {
+                    *reinterpret_cast<bf16x4*>(Ph + 4 * pl) = hi;
+                    *reinterpret_cast<bf16x4*>(Pl + 4 * pl) = lo;
                 }
             }
         }
@@ -566,10 +583,11 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
 
 template <int AFF, int ACT, int RP>
 static void launch_halo_bd_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int nkc, int vec_out,
-                                const halo_geom& g, int dbuf) {
+                                const halo_geom& g, int dbuf, int tab_off) {
     static dyn_lds_cache attr;
     (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_halo3_bd_kernel<AFF, ACT, RP>), lds);
-    hipLaunchKernelGGL((conv_halo3_bd_kernel<AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, nkc, vec_out, g, dbuf);
+    hipLaunchKernelGGL((conv_halo3_bd_kernel<AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, nkc, vec_out, g, dbuf,
+                       tab_off);
 }
 
 static inline int halo_mode(const ga_conv_desc& d) {
@@ -612,6 +630,7 @@ static int halo_geometry(const ga_conv_desc& d, const int BM, halo_geom& g) {
     g.fd_pw = make_fastdiv(g.PW);
     g.fd_thwo = make_fastdiv(g.TH * g.TW);
     g.fd_tw = make_fastdiv(g.TW);
+    g.fd_is = make_fastdiv(g.IS);
     return GA_OK;
 }
 
@@ -663,13 +682,18 @@ static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out
     if (splits > nkc) return GA_E_UNSUPPORTED;
     const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
     const size_t patch = (size_t)2 * g.NI * g.IS * 2;                   // hi + lo planes of one buffer, bytes
-    const int dbuf = 2 * patch <= 80 * 1024 ? 1 : 0;                    // two buffers when two workgroups per CU still fit
-    size_t lds = (dbuf ? 2 : 1) * patch;
-    if (lds > 160 * 1024) return GA_E_UNSUPPORTED;
+    const int mode = halo_mode(d);
+    const int rp = (g.P * 8 + 255) >> 8;                                // patch slots per thread
+    const size_t tab = (size_t)rp * 256 * 6                             // slot tables: global offsets (int) + LDS offsets (short)
+                       + (mode >= 0x10 ? (size_t)2 * (mode == 0x20 ? g.NI : 1) * d.C1 * sizeof(float) : 0);      // prologue table
+    const int dbuf = 2 * patch + tab <= 80 * 1024 ? 1 : 0;              // two buffers when two workgroups per CU still fit
+    const int tab_off = (int)(((dbuf ? 2 : 1) * patch + 15) / 16 * 4);  // floats, 16-byte aligned
+    size_t lds = (size_t)tab_off * 4 + tab;
+    if (lds > 80 * 1024) return GA_E_UNSUPPORTED;                       // (two workgroups per CU are the kernel's launch bounds)
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
-#define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf)
+#define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf, tab_off)
     if (g.P > 9 * 32) return GA_E_UNSUPPORTED;                          // row-segment tiles of wide images: the LDS-staged kernel
     switch (halo_mode(d)) {
         case 0x00: GA_HBD(0, GA_ACT_NONE); break;
