@@ -94,27 +94,23 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
     const __amdgpu_buffer_rsrc_t rsrcWh = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_hi), 0, d.w_bytes / 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcWl = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(d.w_lo), 0, d.w_bytes / 2, 0x00020000);
 
-    // ---- patch slots: slot s = tid + 256 j -> patch pixel s >> 3, channel quad s & 7 (= c4)
-    int pbase[RPMAX], plds[RPMAX];
-    int prow[AFF == 2 ? RPMAX : 1];                         // AFF == 2: offset of the slot's image row in pro_scale / pro_shift
-    unsigned okbits = 0;
+    // ---- patch slots: slot s = tid + 256 j -> patch pixel s >> 3, channel quad s & 7 (= c4).  Per slot: the global byte offset
+    // (INV: padding / outside the batch) and one packed word — LDS element offset (bits 0..19), image within the tile (20..23),
+    // "no such patch pixel" (30)
+    int pbase[RPMAX];
+    unsigned pmeta[RPMAX];
 #pragma unroll
     for (int j = 0; j < RPMAX; ++j) {
         const int pp = (tid + 256 * j) >> 3;
         int off = INV;
-        plds[j] = -1;
-        if (AFF == 2) prow[j] = 0;
+        pmeta[j] = 1u << 30;
         if (j < rp && pp < g.P) {
             const int img = fd_div(pp, g.fd_phpw);
             const int rem = pp - img * g.PH * g.PW;
             const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
-            plds[j] = img * g.IS + py * g.RS + px * LDH + 4 * c4;
+            pmeta[j] = (unsigned)(img * g.IS + py * g.RS + px * LDH + 4 * c4) | ((unsigned)img << 20);
             const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
-            if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) {
-                off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
-                okbits |= 1u << j;
-                if (AFF == 2) prow[j] = n * C + 4 * c4;
-            }
+            if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
         }
         pbase[j] = off;
     }
@@ -165,8 +161,9 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
                     }
                 }
                 if (AFF == 2) {     // per-(image, channel) scale / shift: small and L2-resident, fetched as the slot is converted
-                    const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow[j] + cur_chunk * HK);
-                    const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow[j] + cur_chunk * HK);
+                    const int prow = min(n_first + (int)((pmeta[j] >> 20) & 15u), d.N - 1) * C + 4 * c4 + cur_chunk * HK;
+                    const floatx4 ps = *reinterpret_cast<const floatx4*>(d.pro_scale + prow);
+                    const floatx4 pt = *reinterpret_cast<const floatx4*>(d.pro_shift + prow);
                     v = v * ps + pt;
                 }
                 if (ACT == GA_ACT_SILU) {
@@ -182,12 +179,12 @@ conv_halo3_kernel(const ga_conv_desc d, const int tilesN, const int M, const int
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
-                if (AFF != 0) v = (okbits >> j) & 1u ? v : zero;        // only a shift un-zeroes the padding
+                if (AFF != 0) v = pbase[j] != INV ? v : zero;           // only a shift un-zeroes the padding
                 const bf16x4 hi = __builtin_convertvector(v, bf16x4);
                 const bf16x4 lo = __builtin_convertvector(v - __builtin_convertvector(hi, floatx4), bf16x4);
-                if (plds[j] >= 0) {
-                    *reinterpret_cast<bf16x4*>(Ph + plds[j]) = hi;
-                    *reinterpret_cast<bf16x4*>(Pl + plds[j]) = lo;
+                if (!(pmeta[j] & (1u << 30))) {
+                    *reinterpret_cast<bf16x4*>(Ph + (pmeta[j] & 0xfffffu)) = hi;
+                    *reinterpret_cast<bf16x4*>(Pl + (pmeta[j] & 0xfffffu)) = lo;
                 }
             }
         }

@@ -327,7 +327,6 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_fwd_kernel(const ga_
         __builtin_amdgcn_sched_barrier(0);
         wa.issue(g1h, g1l, C, h2, tid);
         wq.issue(g2h, g2l, d.Hd, h1, tid);
-        taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o + h1);
         // ---- A: depthwise 5x5 of chunk ch
         floatx4 a[SW];
         dw_tile<BH, BW>(a, P1 + win * DC_PS + 4 * c4, wS + 4 * c4, gm.PW);
@@ -383,7 +382,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_fwd_kernel(const ga_
         DC_T(1)
         __syncthreads();
         wa.store(W1h, W1l, tid);
-        if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
+        // the next chunk's taps travel during phase C only (every depthwise read of this chunk's is behind the barrier above):
+        // four registers that are free in phases A and B, where the kernel is at its register limit
+        taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o + h1);
         DC_T(2)
         // ---- C: GEMM2 of chunk ch  ||  SiLU(t1 of chunk ch + 1) -> P1.  One scheduling region per (output tile, k step): 6 / 3 MFMAs
         // beside the SiLU of 4 / 1 accumulator elements.
@@ -426,6 +427,7 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_fwd_kernel(const ga_
             }
         }
         DC_T(3)
+        if (tid < 200) *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
         __syncthreads();
         wq.store(W2h, W2l, tid);
         DC_T(4)
@@ -477,13 +479,9 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_bwd_kernel(const ga_
     const __bf16* g2l = reinterpret_cast<const __bf16*>(d.w2_lo);
 
     WA wa, wq;
-    floatx4 taps = zero, tapsT = zero;
     wa.issue(g1h, g1l, C, 0, tid);
     wq.issue(g2h, g2l, C, 0, tid);
-    if (tid < 200) {
-        taps = *reinterpret_cast<const floatx4*>(d.wd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
-        tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + (size_t)(tid >> 3) * d.Hd + 4 * c4);
-    }
+    const size_t tap_o = (size_t)(tid < 200 ? (tid >> 3) : 0) * d.Hd + 4 * c4;     // threads >= 200 load tap 0 again and drop it
 
     for (int i = tid; i < plane_px * (DC_PS / 4); i += NTHR) reinterpret_cast<floatx4*>(P1)[i] = zero;
 
@@ -523,25 +521,16 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_bwd_kernel(const ga_
         const int h0 = ch * DC_CH;
         wa.store(W1h, W1l, tid);
         wq.store(W2h, W2l, tid);
-        if (tid < 200) {
-            *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
-            *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) = tapsT;
-        }
         __syncthreads();
         DC_T(0)
-        // the small loads first: a wait on them must not wait on the weight prefetch behind them (vmcnt retires in order)
+        // the small loads first: a wait on them must not wait on the weight prefetch behind them (vmcnt retires in order).  The
+        // chunk's depthwise taps travel during phase (a) only and reach LDS in front of its closing barrier: eight registers
+        // that are free in phases (b) .. (f), where the kernel is at its register limit
         const float b1v = d.b1[h0 + lrow];
         const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
+        const floatx4 taps = *reinterpret_cast<const floatx4*>(d.wd + tap_o + h0);
+        const floatx4 tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + tap_o + h0);
         __builtin_amdgcn_sched_barrier(0);
-        {   // straight-line code (the last chunk prefetches itself again): behind a branch the compiler can no longer count the
-            // loads in flight and waits for ALL of them at the first use of b1v — 3 K clocks per chunk
-            const int h1 = min(h0 + DC_CH, (nch - 1) * DC_CH);
-            wa.issue(g1h, g1l, C, h1, tid);
-            wq.issue(g2h, g2l, C, h1, tid);
-            const size_t to = (size_t)(tid < 200 ? (tid >> 3) : 0) * d.Hd + h1 + 4 * c4;
-            taps = *reinterpret_cast<const floatx4*>(d.wd + to);
-            tapsT = *reinterpret_cast<const floatx4*>(d.wd_bwd + to);
-        }
         // ---- (a) recompute t1c -> P4, silu(t1c) -> P1
         floatx16 t1[TMW];
 #pragma unroll
@@ -559,6 +548,10 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_bwd_kernel(const ga_
                 P4[row * DC_PS + lrow] = sg * (1.0f + v * (1.0f - sg));
                 P1[prow[i][r >> 2] + (r & 3) * DC_PS] = v * sg;
             }
+        if (tid < 200) {
+            *reinterpret_cast<floatx4*>(wS + (tid >> 3) * DC_CH + 4 * c4) = taps;
+            *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) = tapsT;
+        }
         DC_T(1)
         __syncthreads();
         DC_T(2)
@@ -612,6 +605,13 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) dec_cell_bwd_kernel(const ga_
         DC_T(4)
         __syncthreads();                // every strip is done reading silu(t1c)
         DC_T(5)
+        {   // the next chunk's weights fly during phases (d) .. (f) and land in LDS at the top of the next chunk: their staging
+            // registers are free in (a) .. (c), where the kernel is at its register limit.  Straight-line code (the last chunk
+            // prefetches itself again): behind a branch the compiler can no longer count the loads in flight
+            const int h1 = min(h0 + DC_CH, (nch - 1) * DC_CH);
+            wa.issue(g1h, g1l, C, h1, tid);
+            wq.issue(g2h, g2l, C, h1, tid);
+        }
         // ---- (d) the plane now carries W2c^T dt3 ...
 #pragma unroll
         for (int i = 0; i < TMW; ++i)

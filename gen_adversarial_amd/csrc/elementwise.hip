@@ -871,10 +871,14 @@ __global__ void __launch_bounds__(256) gconv_kernel(const ga_gconv_desc d, const
     }
 }
 
-// one thread = one output pixel x ALL cg output channels of one group (grid.y); the group's weights sit in LDS and are read
-// as wave-wide broadcasts, the pixel's input channels come from global memory once per tap: 4*cg FMAs per LDS read
+// one thread = one output pixel x ALL cg output channels of one group (grid.y), OB of them at a time; the group's weights sit in
+// LDS and are read as wave-wide broadcasts, the pixel's input channels come from global memory (L1 after the first output block)
+// once per tap and block: 4*OB FMAs per LDS read.  OB = 8 keeps the 32-wide groups of ResNeXt's layer 4 in registers (the
+// one-block form held 32 accumulators plus an unrolled 8 x 32 weight window: 466 spilled registers); every output still sums
+// its taps and channels in the same order.
 template <int CG>
 __global__ void __launch_bounds__(256) gconv_group_kernel(const ga_gconv_desc d, const long npix) {
+    constexpr int OB = CG < 8 ? CG : 8;
     extern __shared__ __attribute__((aligned(16))) float gw[];          // [CG out][KH*KW][CG in]
     const int g = blockIdx.y, taps = d.KH * d.KW, K = taps * CG;
     for (int i = threadIdx.x * 4; i < CG * K; i += 256 * 4)
@@ -884,42 +888,45 @@ __global__ void __launch_bounds__(256) gconv_group_kernel(const ga_gconv_desc d,
     if (p >= npix) return;
     const int wo = (int)(p % d.Wo); long q = p / d.Wo;
     const int ho = (int)(q % d.Ho); const int n = (int)(q / d.Ho);
-    float acc[CG];
+    const size_t ob = (size_t)p * d.C + g * CG;
+#pragma unroll 1
+    for (int o0 = 0; o0 < CG; o0 += OB) {
+        float acc[OB];
 #pragma unroll
-    for (int o = 0; o < CG; ++o) acc[o] = d.bias ? d.bias[g * CG + o] : 0.f;
-    for (int kh = 0; kh < d.KH; ++kh) {
-        const int h = ho * d.stride - d.pad + kh;
-        if (h < 0 || h >= d.Hi) continue;
-        for (int kw = 0; kw < d.KW; ++kw) {
-            const int w = wo * d.stride - d.pad + kw;
-            if (w < 0 || w >= d.Wi) continue;
-            const float* xp = d.x + (((size_t)n * d.Hi + h) * d.Wi + w) * d.C + g * CG;
-            const float* wp = gw + (kh * d.KW + kw) * CG;
+        for (int o = 0; o < OB; ++o) acc[o] = d.bias ? d.bias[g * CG + o0 + o] : 0.f;
+        for (int kh = 0; kh < d.KH; ++kh) {
+            const int h = ho * d.stride - d.pad + kh;
+            if (h < 0 || h >= d.Hi) continue;
+            for (int kw = 0; kw < d.KW; ++kw) {
+                const int w = wo * d.stride - d.pad + kw;
+                if (w < 0 || w >= d.Wi) continue;
+                const float* xp = d.x + (((size_t)n * d.Hi + h) * d.Wi + w) * d.C + g * CG;
+                const float* wp = gw + (size_t)o0 * K + (kh * d.KW + kw) * CG;
+#pragma unroll 2
+                for (int c = 0; c < CG; c += 4) {
+                    floatx4 v = ld4(xp + c);
+                    if (d.pro_act) {
 #pragma unroll
-            for (int c = 0; c < CG; c += 4) {
-                floatx4 v = ld4(xp + c);
-                if (d.pro_act) {
+                        for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
+                    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_fwd_fast(v[e], d.pro_act);
-                }
-#pragma unroll
-                for (int o = 0; o < CG; ++o) {
-                    const floatx4 w4 = *reinterpret_cast<const floatx4*>(wp + o * K + c);
-                    acc[o] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+                    for (int o = 0; o < OB; ++o) {
+                        const floatx4 w4 = *reinterpret_cast<const floatx4*>(wp + o * K + c);
+                        acc[o] += v[0] * w4[0] + v[1] * w4[1] + v[2] * w4[2] + v[3] * w4[3];
+                    }
                 }
             }
         }
-    }
-    const size_t ob = (size_t)p * d.C + g * CG;
 #pragma unroll
-    for (int o = 0; o < CG; o += 4) {
-        floatx4 r = {acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
-        if (d.dact_x) {
-            const floatx4 u = ld4(d.dact_x + ob + o);
+        for (int o = 0; o < OB; o += 4) {
+            floatx4 r = {acc[o], acc[o + 1], acc[o + 2], acc[o + 3]};
+            if (d.dact_x) {
+                const floatx4 u = ld4(d.dact_x + ob + o0 + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] *= act_bwd_fast(u[e], d.dact_act);
+                for (int e = 0; e < 4; ++e) r[e] *= act_bwd_fast(u[e], d.dact_act);
+            }
+            *reinterpret_cast<floatx4*>(d.y + ob + o0 + o) = r;
         }
-        *reinterpret_cast<floatx4*>(d.y + ob + o) = r;
     }
 }
 

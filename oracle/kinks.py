@@ -77,26 +77,33 @@ class Replay:
             self.unmatched.append((what, tuple(x.shape)))
             return None
         best, best_agree = None, 0.0
-        for e in self._shaped(x):
-            agree = ((e > 0) == own).float().mean().item()
-            if agree > best_agree:
-                best, best_agree = e, agree
-        # a match may disagree on at most 0.1 % of the decisions (one, for small tensors); tensors with fewer than 48 decisions
-        # are never matched by agreement (a chance agreement would replay a stranger's decisions)
-        ok = (best is not None and own.numel() >= 48 and
-              (1.0 - best_agree) * own.numel() <= max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5)
-        if not ok:
-            best = None
-            if x.shape[2:] == (1, 1):
-                # [N, F] tensors (squeeze-and-excite hidden units of any width): the other implementation hands them over in call
-                # order; a site takes the next one of its shape that disagrees on at most two decisions
-                for i in range(self.small_pos, min(self.small_pos + 4, len(self.small))):
-                    e = self.small[i]
-                    if tuple(e.shape) == tuple(x.shape[:2]) and int(((e > 0) != own[:, :, 0, 0]).sum()) <= 2:
-                        best, self.small_pos = e[:, :, None, None], i + 1
-                        break
-            if best is None:
-                self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)))
+        if x.shape[2:] == (1, 1):
+            # [N, F] tensors (squeeze-and-excite hidden units of any width): the other implementation hands them over in call
+            # order; a site takes the next one of its shape that disagrees on at most two decisions.  Tried FIRST, so that the
+            # position in the list follows the call order whatever the width (a wide site matched by agreement below would
+            # leave it behind)
+            for i in range(self.small_pos, min(self.small_pos + 4, len(self.small))):
+                e = self.small[i]
+                if tuple(e.shape) == tuple(x.shape[:2]) and int(((e > 0) != own[:, :, 0, 0]).sum()) <= 2:
+                    best, self.small_pos = e[:, :, None, None], i + 1
+                    break
+        if best is None:
+            for e in self._shaped(x):
+                agree = ((e > 0) == own).float().mean().item()
+                if agree > best_agree:
+                    best, best_agree = e, agree
+            # a match may disagree on at most 0.1 % of the decisions (one, for small tensors); tensors with fewer than 48 decisions
+            # are never matched by agreement (a chance agreement would replay a stranger's decisions)
+            ok = (best is not None and own.numel() >= 48 and
+                  (1.0 - best_agree) * own.numel() <= max(1.0, (1.0 - self.min_agree) * own.numel()) + 0.5)
+            if not ok:
+                note = ''
+                if x.shape[2:] == (1, 1) and self.small:        # diagnosis: the nearest handed-over tensor of this shape, anywhere
+                    dis = [(int(((e > 0) != own[:, :, 0, 0]).sum()), i) for i, e in enumerate(self.small) if tuple(e.shape) == tuple(x.shape[:2])]
+                    if dis:
+                        k, i = min(dis)
+                        note = f'nearest handed-over tensor: {k} decisions differ at list position {i} (cursor {self.small_pos}); max |x| {float(x.abs().max()):.3e}'
+                self.unmatched.append((what, tuple(x.shape), round(best_agree, 4)) + ((note,) if note else ()))
                 return None
         dec = best > 0
         diff = dec != own
