@@ -407,8 +407,8 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
             *reinterpret_cast<floatx4*>(ptab + (TI + img) * C + 4 * cq) = *reinterpret_cast<const floatx4*>(d.pro_shift + row + 4 * cq);
         }
     }
-    // (the barrier in front of the K loop orders these writes before the first reads of other threads' entries; a thread's own
-    // slot entries are read by itself only)
+    // a thread's slot entries are read by itself only; the prologue table is read by everybody in the first finish_patch below
+    if (AFF != 0) __syncthreads();
     int fragA[TM];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
