@@ -67,9 +67,16 @@ ROCPROF = '/opt/rocm/bin/rocprofv3'
 
 
 def pmc_child(args):
-    """--pmc-child: what the two counter passes profile — ONE forward + backward replay of the chunk plans (the launches
-    `roofline.achieved` is about).  Started by measure_pmc_traffic() under `rocprofv3 --pmc <counter> --kernel-trace`."""
-    eng, _ = build_model('cuda:0', args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
+    """--pmc-child: what the two counter passes profile — ONE forward + backward replay of the plans of --pmc-workload (the
+    launches `roofline.achieved` is about).  Started by measure_pmc_traffic() under `rocprofv3 --pmc <counter> --kernel-trace`."""
+    if args.pmc_workload == 'e4e':
+        eng, _ = build_e4e_defender('cuda:0', 32, args.eot, args.precision)
+        eng.noise.normal_()
+        eng.noise_coef.copy_(eng.noise_eps / eng.noise.flatten(1).norm(dim=1))
+    elif args.pmc_workload == 'trans':
+        eng, _ = build_trans_defender('cuda:0', 64, args.eot, args.precision)
+    else:
+        eng, _ = build_model('cuda:0', args.chunk_rows, args.eot, seed=0, precision=args.precision, share_encoder=args.share_encoder)
     eng.x_in.uniform_()
     for e in eng.eps:
         e.normal_()
@@ -79,7 +86,7 @@ def pmc_child(args):
     torch.cuda.synchronize()
 
 
-def measure_pmc_traffic(args):
+def measure_pmc_traffic(args, workload='nvae'):
     """HBM bytes per conv launch, measured in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: the TCC has
     4 counter slots, they cost 3 + 2) over a child process that replays one chunk's forward + backward plan.  Units and gfx950
     correction as /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes: the counters are in KB; FETCH_SIZE reports
@@ -98,8 +105,8 @@ def measure_pmc_traffic(args):
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix=f'ga_pmc_{counter.lower()}_', dir=os.environ.get('TMPDIR', '/tmp'))
         cmd = [exe, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--',
-               sys.executable, os.path.abspath(__file__), '--pmc-child', '--chunk-rows', str(args.chunk_rows), '--eot', str(args.eot),
-               '--precision', args.precision] + (['--share-encoder'] if args.share_encoder else [])
+               sys.executable, os.path.abspath(__file__), '--pmc-child', '--pmc-workload', workload, '--chunk-rows', str(args.chunk_rows),
+               '--eot', str(args.eot), '--precision', args.precision] + (['--share-encoder'] if args.share_encoder else [])
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.pmc_timeout, cwd=os.environ.get('TMPDIR', '/tmp'))
         except subprocess.TimeoutExpired:
@@ -125,7 +132,9 @@ def measure_pmc_traffic(args):
     write, nw = sums['WRITE_SIZE']
     per_launch = 2.0 * fetch * 1024.0 / nf + write * 1024.0 / nw
     return per_launch, (f'measured in this run before the timed region: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, '
-                        f'--kernel-trace only) over one forward + backward replay of a {args.chunk_rows}-row chunk plan in a child process; '
+                        f'--kernel-trace only) over one forward + backward replay of '
+                        + {'nvae': f'a {args.chunk_rows}-row chunk plan', 'e4e': 'the 32-row configs[2] plan', 'trans': 'the 64-row configs[4] plan'}[workload]
+                        + f' in a child process; '
                         f'{nf} conv launches; bytes = 2 x FETCH_SIZE KB (gfx950 counts half of wide coalesced reads) + WRITE_SIZE KB')
 
 
@@ -382,7 +391,7 @@ def class_jacobian_measurement(args, device, store):
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION
     res = {}
-    for images, K in ((1, 16), (16, 4)):
+    for images, K in (((1, 16), (16, 4)) if args.class_jacobian_batch else ((1, 16),)):
         rows = images * args.eot
         e1, model = build_model(device, rows, args.eot, seed=0, precision=args.precision, share_encoder=True, store=store)
         sd, vsd, vspec, alphas = model
@@ -411,7 +420,7 @@ def class_jacobian_measurement(args, device, store):
     return res
 
 
-def build_trans_defender(device, rows, eot, precision):
+def build_trans_defender(device, rows, eot, precision, parts=False):
     """BASELINE.json configs[4] (configs/ours_learned_blur_cars.yaml: 16 learned alphas x 0.7, Gaussian blur of the input): the
     Style-Transformer encoder (IR-SE50 at 192 x 256 + 3 decoder layers over 16 queries) + StyleGAN2-512 + ResNeXt-50 32x4d at
     128 px, random weights of the reference architecture"""
@@ -430,6 +439,8 @@ def build_trans_defender(device, rows, eot, precision):
     eng = Engine.bare(rows, device=device, precision=precision, rep=eot, resolution=(3, 128, 128), alphas=alphas,
                       noise_eps=float(y['initial_noise_eps']), blur=bool(y['gaussian_blur_input']), share_encoder=False)
     eng.build_trans_defense(tsd, tspec, gsd, gspec, avg, csd, cspec, pool_to=128)
+    if parts:       # tests/test_fullsize_configs_gpu.py: the same weights for the CPU oracle
+        return eng, y, (tsd, tspec, gsd, gspec, avg, csd, cspec, alphas)
     return eng, y
 
 
@@ -438,6 +449,7 @@ def trans_defender_measurement(args, device, rows=64, eot=32):
     plan run, literal x.repeat(eot) path.  (The config's "bf16" is the reference's autocast setting; arithmetic here is the
     engine's fp32-class split-bf16 mode.)"""
     eng, y = build_trans_defender(device, rows, eot, args.precision)
+    pmc = getattr(args, 'defender_pmc', {}).get('trans', (None, 'PMC passes skipped'))
     n_img = rows // eot
     g = torch.Generator(device=device).manual_seed(9)
     x = torch.rand(n_img, 3, 128, 128, device=device, generator=g)
@@ -468,17 +480,18 @@ def trans_defender_measurement(args, device, rows=64, eot=32):
                    f'gradient), alphas ours_learned_blur_cars.yaml, {len(eng.fwd)} + {len(eng.bwd)} launches per plan, '
                    f'{eng.bytes / 1e9:.0f} GB of activations + weights',
            'roofline': {'bound': 'mfma', 'kernel': 'ga::conv_* (implicit-GEMM conv family)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': achieved / peak, 'traffic': None, 'launches_per_plan': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                        'frac': achieved / peak, 'traffic': pmc[0], 'traffic_note': pmc[1],
+                        'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
+                        'launches_per_plan': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_plan': flops / 1e9, 'conv_ms_per_plan': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
     del eng
     return res
 
 
-def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
+def build_e4e_defender(device, rows, eot, precision, parts=False):
     """BASELINE.json configs[2] (configs/ours_cosine_noise_gender.yaml: 18 cosine alphas, initial_noise_eps 4.0): IR-SE50 e4e
-    encoder on 256 px -> 18 x 512 latents mixed with mapped noise -> StyleGAN2 at 1024 px -> face_pool 256 -> ResNet-50, forward
-    + backward-to-input (one PGD-Linf iteration), 64 defender rows per step as two 32-row plan runs (1 image x EoT 32 each; a
-    32-row plan holds ~100 GB of activations).  Random weights, synthetic images."""
+    encoder on 256 px -> 18 x 512 latents mixed with mapped noise -> StyleGAN2 at 1024 px -> face_pool 256 -> ResNet-50, random
+    weights of the reference architecture"""
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.e4e_spec import build_e4e_spec, init_e4e_state_dict
     from gen_adversarial_amd.resnet_spec import build_resnet_spec, init_resnet_state_dict
@@ -491,9 +504,19 @@ def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
     gsd = init_stylegan_state_dict(gspec, 1)
     cspec, csd = build_resnet_spec(2), init_resnet_state_dict(2, 1, 2)
     avg = 0.1 * torch.randn(18, 512, generator=torch.Generator().manual_seed(5))
-    eng = Engine.bare(chunk, device=device, precision=args.precision, rep=eot, resolution=(3, 256, 256), alphas=alphas,
+    eng = Engine.bare(rows, device=device, precision=precision, rep=eot, resolution=(3, 256, 256), alphas=alphas,
                       noise_eps=float(y['initial_noise_eps']))
     eng.build_e4e_defense(esd, espec, gsd, gspec, avg, csd, cspec, pool_to=256)
+    if parts:       # tests/test_fullsize_configs_gpu.py: the same weights for the CPU oracle
+        return eng, y, (esd, espec, gsd, gspec, avg, csd, cspec, alphas)
+    return eng, y
+
+
+def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
+    """configs[2] on one GPU: forward + backward-to-input (one PGD-Linf iteration), 64 defender rows per step as two 32-row plan
+    runs (1 image x EoT 32 each; a 32-row plan holds ~100 GB of activations).  Random weights, synthetic images."""
+    eng, y = build_e4e_defender(device, chunk, eot, args.precision)
+    pmc = getattr(args, 'defender_pmc', {}).get('e4e', (None, 'PMC passes skipped'))
     n_img = rows // eot
     g = torch.Generator(device=device).manual_seed(7)
     x = torch.rand(n_img, 3, 256, 256, device=device, generator=g)
@@ -528,7 +551,9 @@ def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
                    f'PGD step (forward + input gradient), initial_noise_eps {y["initial_noise_eps"]}, alphas ours_cosine_noise_gender.yaml, '
                    f'{len(eng.fwd)} + {len(eng.bwd)} launches per {chunk}-row plan, {eng.bytes / 1e9:.0f} GB of activations + weights',
            'roofline': {'bound': 'mfma', 'kernel': 'ga::conv_* (implicit-GEMM conv family)', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                        'frac': achieved / peak, 'traffic': None, 'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
+                        'frac': achieved / peak, 'traffic': pmc[0], 'traffic_note': pmc[1],
+                        'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
+                        'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_chunk': flops / 1e9, 'conv_ms_per_chunk': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
     del eng
     return res
@@ -620,6 +645,10 @@ def main():
     ap.add_argument('--precision', choices=['bf16x3', 'fp32'], default='bf16x3',
                     help="dense contractions: 'bf16x3' = 3 bf16 MFMAs per product (logits within ~2e-5 of fp32), 'fp32' = exact f32 MFMA")
     ap.add_argument('--pmc-child', action='store_true', help='internal: the process the PMC passes profile (see measure_pmc_traffic)')
+    ap.add_argument('--pmc-workload', choices=['nvae', 'e4e', 'trans'], default='nvae', help='internal: which plans --pmc-child replays')
+    ap.add_argument('--class-jacobian-batch', action='store_true',
+                    help='secondary.class_jacobian: also time the 16-image batch (512 rows, K = 4), about a minute more')
+    ap.add_argument('--no-defender-pmc', action='store_true', help='skip the PMC passes over the configs[2] / configs[4] defender plans')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc passes (roofline.traffic = null)')
     ap.add_argument('--pmc-timeout', type=int, default=240)
     ap.add_argument('--robust-acc-images', type=int, default=512,
@@ -643,10 +672,15 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N starts them '
                          'itself; under torch.distributed.run pass the same N)')
     pmc_bytes, pmc_note = None, 'skipped'
+    args.defender_pmc = {}
     if rank == 0 and world == 1 and not args.no_pmc and not args.stub_engine:
         log('PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one chunk replay in a child process) ...')
         pmc_bytes, pmc_note = measure_pmc_traffic(args)           # before this process initialises the GPU
         log(f'PMC: {pmc_bytes} bytes per conv launch ({pmc_note[:80]})')
+        if not args.no_secondary and not args.no_defender_pmc:
+            for w in ('e4e', 'trans'):
+                args.defender_pmc[w] = measure_pmc_traffic(args, w)
+                log(f'PMC ({w} defender): {args.defender_pmc[w][0]} bytes per conv launch')
     if args.no_secondary:
         args.no_rows256 = args.no_shared_variant = True
     if args.stub_engine:

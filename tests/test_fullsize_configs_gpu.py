@@ -1,0 +1,146 @@
+"""
+BASELINE.json configs[2] and configs[4] AT THEIR OWN SIZES AND SETTINGS against the CPU oracle:
+
+  configs[2]  configs/ours_cosine_noise_gender.yaml: IR-SE50 e4e encoder on 256 x 256 -> 18 x 512 codes mixed with the mapped
+              noise by the yaml's 18 cosine alphas -> StyleGAN2 at 1024 x 1024 -> face_pool 256 -> ResNet-50 (2 classes),
+              initial_noise_eps 4.0 (so the EoT replicas differ from the first op on: literal x.repeat(eot) path), one image x
+              EoT 32 = the 32-row plan bench.py times;
+  configs[4]  configs/ours_learned_blur_cars.yaml: Gaussian blur (k = 31 at 128 px) -> resize 256 / crop -> Style-Transformer
+              encoder (IR-SE50 at 192 x 256 + 3 decoder layers over 16 queries) -> StyleGAN2 at 512 -> pool / band / resize 128 ->
+              ResNeXt-50 32x4d (4 classes), the yaml's 16 learned alphas x 0.7, two images x EoT 32 = the 64-row plan bench.py times.
+
+Random weights of the reference architectures (no checkpoint exists offline).  Rows are independent, so the oracle is run on
+rows 0..K-1 of the plan (image 0 under its first K noise / latent draws) and the cotangent is zero on the other rows:
+logits and purified image at 1e-3 (north_star), the input gradient on every element given the engine's ReLU / PReLU / LeakyReLU /
+max-pool decisions (tests/gradcheck.py).  Plus the size-independent properties: replicas with equal draws are bitwise equal rows,
+two forwards are bitwise equal, the backward pass is linear in its cotangent, images without a cotangent get no gradient.
+The oracle runs take ~15 s (configs[2], one row forward + backward at 1024 px) per evaluation on the box's 16 cores.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import build_e4e_defender, build_trans_defender   # noqa: E402  (the engines bench.py times, built by the same code)
+
+DEV = 'cuda:0'
+TOL = 1e-3
+
+
+def err(a, b):
+    return (a.detach().float().cpu() - b.detach().float()).abs().max().item()
+
+
+def _properties(eng, rows, rep, ncls, fill, gen):
+    """size-independent properties on the plan as built for the bench; returns (logits, purified) of the last forward"""
+    fill()
+    eng.forward()
+    torch.cuda.synchronize()
+    l0, p0 = eng.logits.view(rows, -1).clone(), eng.purified_nchw().clone()
+    assert torch.isfinite(l0).all() and torch.isfinite(p0).all()
+    eng.forward()
+    torch.cuda.synchronize()
+    assert torch.equal(l0, eng.logits.view(rows, -1)) and torch.equal(p0, eng.purified_nchw()), 'two forwards of one plan differ'
+    grads = []
+    a = torch.randn(rows, ncls, generator=gen).to(DEV)
+    b = torch.randn(rows, ncls, generator=gen).to(DEV)
+    for c in (a, b, a + b):
+        eng.dlogits.view(rows, -1).copy_(c)
+        eng.backward()
+        grads.append(eng.dx.clone())
+    scale = grads[2].abs().max().item()
+    lin = (grads[2] - grads[0] - grads[1]).abs().max().item()
+    print(f'   |dx| {scale:.2e}, backward linearity {lin:.2e}')
+    assert torch.isfinite(grads[2]).all() and scale > 0 and lin < 1e-4 * scale
+    return l0, p0
+
+
+def test_configs2_e4e_defender_32_rows_yaml_alphas_noise_eps_4():
+    from oracle import defender_oracle as D
+    rows, rep, k = 32, 32, 2
+    eng, y, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = build_e4e_defender(DEV, rows, rep, 'bf16x3', parts=True)
+    assert float(y['initial_noise_eps']) == 4.0 and len(alphas) == 18 and not eng.share_encoder and eng.noise is not None
+    assert (gspec.size, espec.n_styles if hasattr(espec, 'n_styles') else 18) == (1024, 18)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.rand(rows // rep, 3, 256, 256, generator=gen)
+    z = torch.randn(rows, 18, 512, generator=gen)
+    nz = torch.randn(rows, 3, 256, 256, generator=gen)
+    z[k] = z[0]                      # replica k repeats replica 0's draws: its row must equal row 0 bit for bit
+    nz[k] = nz[0]
+
+    def fill():
+        eng.x_in.copy_(x.to(DEV))
+        eng.eps[0].copy_(z.to(DEV))
+        eng.noise.copy_(nz.to(DEV))
+        eng.noise_coef.copy_((eng.noise_eps / nz.flatten(1).norm(dim=1)).to(DEV))
+    print(f'configs[2] plan: {len(eng.fwd)} + {len(eng.bwd)} ops, {eng.bytes / 1e9:.0f} GB')
+    logits, purified = _properties(eng, rows, rep, 2, fill, gen)
+    assert torch.equal(logits[k], logits[0]) and torch.equal(purified[k], purified[0])
+    assert purified.shape == (rows, 3, 256, 256)
+
+    # ---- the oracle on rows 0..k-1
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cot = torch.zeros(rows, 2)
+    cot[:k] = torch.randn(k, 2, generator=gen)
+
+    def call(t):
+        pre = D.add_gaussian_noise(t.repeat(k, 1, 1, 1), nz[:k], 4.0)
+        return D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, pre, alphas, z[:k], 256)
+    with torch.no_grad():
+        lg, pur = call(x)
+    e_l, e_p = err(logits[:k], lg), err(purified[:k], pur)
+    print(f'configs[2] 32-row plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} (|logits| {lg.abs().max().item():.1f}) purified {e_p:.2e}')
+    assert e_l < TOL * max(1.0, lg.abs().max().item()) and e_p < TOL
+    eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
+    eng.backward()
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda t: (call(t)[0] * cot[:k]).sum(), x, eng.dx, 1e-3,
+                                       'configs[2] input gradient of rows 0..1 inside the 32-row plan', min_matched=20, rows=slice(0, k))
+
+
+def test_configs4_trans_defender_64_rows_yaml_alphas_blur():
+    from oracle import defender_oracle as D, trans_oracle as T
+    rows, rep, k = 64, 32, 2
+    eng, y, (tsd, tspec, gsd, gspec, avg, csd, cspec, alphas) = build_trans_defender(DEV, rows, rep, 'bf16x3', parts=True)
+    assert bool(y['gaussian_blur_input']) and eng.blur and len(alphas) == 16 and abs(alphas[0] - 0.7) < 1e-12 and gspec.size == 512
+    assert D.blur_kernel_size(128) == 31
+    gen = torch.Generator().manual_seed(43)
+    n_img = rows // rep
+    x = torch.rand(n_img, 3, 128, 128, generator=gen)
+    z = 0.8 * torch.randn(rows, 16, 512, generator=gen)          # models.py:331: N(0, 0.8)
+    z[k] = z[0]
+
+    def fill():
+        eng.x_in.copy_(x.to(DEV))
+        eng.eps[0].copy_(z.to(DEV))
+    print(f'configs[4] plan: {len(eng.fwd)} + {len(eng.bwd)} ops, {eng.bytes / 1e9:.0f} GB')
+    logits, purified = _properties(eng, rows, rep, 4, fill, gen)
+    assert torch.equal(logits[k], logits[0]) and torch.equal(purified[k], purified[0])
+    assert purified.shape == (rows, 3, 128, 128)
+
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    cot = torch.zeros(rows, 4)
+    cot[:k] = torch.randn(k, 4, generator=gen)
+
+    def call(t):
+        pre = D.apply_gaussian_blur(t).repeat(k, 1, 1, 1)
+        p = T.trans_purify(tsd, tspec, gsd, gspec, avg, pre, alphas, z[:k])
+        return D.resnet_classifier_call(csd, cspec, p), p
+    with torch.no_grad():
+        lg, pur = call(x[:1])
+    e_l, e_p = err(logits[:k], lg), err(purified[:k], pur)
+    print(f'configs[4] 64-row plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} (|logits| {lg.abs().max().item():.1f}) purified {e_p:.2e}')
+    assert e_l < TOL * max(1.0, lg.abs().max().item()) and e_p < TOL
+    eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
+    eng.backward()
+    assert float(eng.dx[1:].abs().max()) == 0.0               # image 1's rows carry no cotangent
+    from gradcheck import assert_grad_given_engine_decisions
+    assert_grad_given_engine_decisions(eng, lambda t: (call(t)[0] * cot[:k]).sum(), x[:1], eng.dx[:1], 1e-3,
+                                       'configs[4] input gradient of rows 0..1 inside the 64-row plan', min_matched=20, rows=slice(0, k))
