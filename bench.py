@@ -420,6 +420,33 @@ def class_jacobian_measurement(args, device, store):
     return res
 
 
+def defender_parity(eng, oracle_call, res_px, n_latent, noise_eps, eps_std=1.0):
+    """parity_vs_oracle of a configs[2] / configs[4] plan AS TIMED: row 0 of the plan (image 0 under seeded draws) against the CPU
+    oracle evaluated on that one row, forward only (tests/test_fullsize_configs_gpu.py holds the gradient comparison)."""
+    if getattr(eng, 'dry_run', False):
+        return None
+    gen = torch.Generator().manual_seed(77)
+    x = torch.rand(eng.x_in.shape[0], 3, res_px, res_px, generator=gen)
+    z = eps_std * torch.randn(eng.rows, n_latent, 512, generator=gen)
+    eng.x_in.copy_(x.to(eng.x_in.device))
+    eng.eps[0].copy_(z.to(eng.x_in.device))
+    nz = None
+    if noise_eps:
+        nz = torch.randn(eng.rows, 3, res_px, res_px, generator=gen)
+        eng.noise.copy_(nz.to(eng.x_in.device))
+        eng.noise_coef.copy_((noise_eps / nz.flatten(1).norm(dim=1)).to(eng.x_in.device))
+    eng.forward()
+    torch.cuda.synchronize()
+    torch.set_num_threads(int(os.environ.get('GA_CPU_THREADS', min(len(os.sched_getaffinity(0)), 16))))   # the one-GPU box's CPU share
+    log(f'   parity: oracle on row 0 ({torch.get_num_threads()} threads) ...')
+    with torch.no_grad():
+        lg, pur = oracle_call(x[:1], z[:1], None if nz is None else nz[:1])
+    return {'rows': 1, 'max_abs_logit_err': float((eng.logits.view(eng.rows, -1)[:1].cpu() - lg).abs().max()),
+            'max_abs_logit': float(lg.abs().max()), 'max_abs_purified_err': float((eng.purified_nchw()[:1].cpu() - pur).abs().max()),
+            'note': 'row 0 of the timed plan vs the CPU oracle on that row (forward); tolerance of the path 1e-3 (relative to max |logit| '
+                    'for logits); gradients: tests/test_fullsize_configs_gpu.py'}
+
+
 def build_trans_defender(device, rows, eot, precision, parts=False):
     """BASELINE.json configs[4] (configs/ours_learned_blur_cars.yaml: 16 learned alphas x 0.7, Gaussian blur of the input): the
     Style-Transformer encoder (IR-SE50 at 192 x 256 + 3 decoder layers over 16 queries) + StyleGAN2-512 + ResNeXt-50 32x4d at
@@ -448,7 +475,7 @@ def trans_defender_measurement(args, device, rows=64, eot=32):
     """configs[4] on one GPU: one PGD-Linf iteration (forward + input gradient) over 2 images x EoT 32 = 64 defender rows in one
     plan run, literal x.repeat(eot) path.  (The config's "bf16" is the reference's autocast setting; arithmetic here is the
     engine's fp32-class split-bf16 mode.)"""
-    eng, y = build_trans_defender(device, rows, eot, args.precision)
+    eng, y, parts = build_trans_defender(device, rows, eot, args.precision, parts=True)
     pmc = getattr(args, 'defender_pmc', {}).get('trans', (None, 'PMC passes skipped'))
     n_img = rows // eot
     g = torch.Generator(device=device).manual_seed(9)
@@ -484,7 +511,15 @@ def trans_defender_measurement(args, device, rows=64, eot=32):
                         'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                         'launches_per_plan': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_plan': flops / 1e9, 'conv_ms_per_plan': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
-    del eng
+    if not args.no_cpu_baseline:
+        from oracle import defender_oracle as D, trans_oracle as T          # the checker, never the thing measured
+        tsd, tspec, gsd, gspec, avg, csd, cspec, alphas = parts
+
+        def call(x1, z1, _):
+            p = T.trans_purify(tsd, tspec, gsd, gspec, avg, D.apply_gaussian_blur(x1), alphas, z1)
+            return D.resnet_classifier_call(csd, cspec, p), p
+        res['parity_vs_oracle'] = defender_parity(eng, call, 128, 16, 0.0, eps_std=0.8)
+    del eng, parts
     return res
 
 
@@ -515,7 +550,7 @@ def build_e4e_defender(device, rows, eot, precision, parts=False):
 def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
     """configs[2] on one GPU: forward + backward-to-input (one PGD-Linf iteration), 64 defender rows per step as two 32-row plan
     runs (1 image x EoT 32 each; a 32-row plan holds ~100 GB of activations).  Random weights, synthetic images."""
-    eng, y = build_e4e_defender(device, chunk, eot, args.precision)
+    eng, y, parts = build_e4e_defender(device, chunk, eot, args.precision, parts=True)
     pmc = getattr(args, 'defender_pmc', {}).get('e4e', (None, 'PMC passes skipped'))
     n_img = rows // eot
     g = torch.Generator(device=device).manual_seed(7)
@@ -555,7 +590,14 @@ def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
                         'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                         'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_chunk': flops / 1e9, 'conv_ms_per_chunk': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
-    del eng
+    if not args.no_cpu_baseline:
+        from oracle import defender_oracle as D                              # the checker, never the thing measured
+        esd, espec, gsd, gspec, avg, csd, cspec, alphas = parts
+
+        def call(x1, z1, n1):
+            return D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, D.add_gaussian_noise(x1, n1, eng.noise_eps), alphas, z1, 256)
+        res['parity_vs_oracle'] = defender_parity(eng, call, 256, 18, eng.noise_eps)
+    del eng, parts
     return res
 
 

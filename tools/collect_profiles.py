@@ -128,6 +128,50 @@ traffic['hbm_bytes_per_attack_row'] = traffic['hot_path_kernels_total_bytes'] / 
 traffic['_note'] = ("'other' = PyTorch kernels of engine construction (zero-filling the activation buffers, weight upload / bf16 split): not on the "
                     "hot path; hbm_bytes_per_attack_row counts the ga:: kernels only")
 res['traffic'] = traffic
+
+# ---- 4. the configs[2] / configs[4] defenders: one forward + backward replay of the plan bench.py times (32-row e4e plan, 64-row
+#         Style-Transformer plan): kernel-trace stats by family, then FETCH_SIZE / WRITE_SIZE passes by family
+for w, rows, what in (('e4e', 32, 'configs[2]: IR-SE50 e4e @256 px -> StyleGAN2-1024 -> ResNet-50, 32-row plan, initial_noise_eps 4.0'),
+                      ('trans', 64, 'configs[4]: blur -> Style-Transformer encoder -> StyleGAN2-512 -> ResNeXt-50 @128 px, 64-row plan')):
+    wchild = BENCH + ['--pmc-child', '--pmc-workload', w, '--eot', '32']
+    d = os.path.join(OUT, f'{w}_trace')
+    shutil.rmtree(d, ignore_errors=True)
+    rc = run([ROCPROF, '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '-o', w, '--'] + wchild, os.path.join(OUT, f'{w}_trace.log'))
+    stats = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)
+    md.append(f'## {what}: one forward + backward replay (`bench.py --pmc-child --pmc-workload {w}`) under --kernel-trace --stats\n')
+    if rc != 0 or not stats:
+        md.append(f'FAILED (rc {rc})\n')
+        continue
+    shutil.copy(stats[0], os.path.join(OUT, f'{tag}_{w}_defender_kernel_stats.csv'))
+    rows_ = [r for r in csv.DictReader(open(stats[0])) if 'ga::' in r['Name']]
+    tot = sum(float(r['TotalDurationNs']) for r in rows_)
+    grp = collections.OrderedDict()
+    for r in rows_:
+        g = grp.setdefault(family(r['Name']), [0, 0.0])
+        g[0] += int(r['Calls'])
+        g[1] += float(r['TotalDurationNs'])
+    shutil.rmtree(d, ignore_errors=True)
+    tr = {}
+    for passname, counter in (('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE')):
+        d = os.path.join(OUT, f'{w}_pmc_{passname}')
+        shutil.rmtree(d, ignore_errors=True)
+        run([ROCPROF, '--pmc', counter, '--kernel-trace', '--output-format', 'csv', '-d', d, '-o', 'pmc', '--'] + wchild,
+            os.path.join(OUT, f'{w}_pmc_{passname}.log'))
+        for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+            for row in csv.DictReader(open(f, newline='')):
+                if 'ga::' in row['Kernel_Name'] and row['Counter_Name'] == counter:
+                    tr.setdefault(family(row['Kernel_Name']), {'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})[counter] += float(row['Counter_Value'])
+        shutil.rmtree(d, ignore_errors=True)
+    md.append(f'ga:: kernels only (engine construction excluded): {tot / 1e6:.1f} ms for {rows} rows\n')
+    md.append('| kernel family | calls | total ms | avg us | % of kernel time | HBM MB (2 x FETCH_SIZE + WRITE_SIZE) | TB/s while running |\n|---|---|---|---|---|---|---|')
+    allb = 0.0
+    for k, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1])[:14]:
+        b = (2 * tr.get(k, {}).get('FETCH_SIZE', 0.0) + tr.get(k, {}).get('WRITE_SIZE', 0.0)) * 1024.0
+        md.append(f'| `{k}` | {c} | {t / 1e6:.1f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} | {b / 1e6:.0f} | {b / t / 1e3 if t else 0:.2f} |')
+    allb = sum((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0 for v in tr.values())
+    md.append(f'\nHBM traffic of the replay: {allb / 1e9:.1f} GB = {allb / rows / 1e6:.0f} MB per attack row\n')
+    res[f'{w}_defender_traffic'] = {'rows': rows, 'hbm_bytes_per_attack_row': allb / rows,
+                                    'by_family': {k: (2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0 for k, v in tr.items()}}
 json.dump(res, open(os.path.join(OUT, f'{tag}_pmc_summary.json'), 'w'), indent=1)
 open(os.path.join(OUT, f'{tag}_kernel_families.md'), 'w').write('\n'.join(md) + '\n')
 print('\n'.join(md))
