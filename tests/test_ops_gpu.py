@@ -256,6 +256,8 @@ def test_conv_halo3(N, H, W, Cin, Cout, act, affine, tile, splits):
     (2, 32, 32, 32, 64, 3, 'none', 1, 1),         # 4 image rows per tile, one channel chunk, ReLU
     (3, 8, 8, 64, 128, 0, 'per_row', 1, 0),       # the SE-gate prologue of conv2^T
     (1, 2, 64, 32, 32, 4, 'none', 1, 0),          # 64-wide rows, LeakyReLU
+    (96, 16, 16, 128, 128, 1, 'affine', 1, 0),    # 192 workgroups in flight: the prologue table is staged by all threads of a
+    (160, 8, 8, 256, 256, 0, 'per_row', 1, 1),    # workgroup and read by all (a missing barrier showed only at this scale)
 ])
 def test_conv_halo3_fragment_weights(N, H, W, Cin, Cout, act, mode, splits, dact):
     """tile 8 (weights read as ready MFMA fragments from ga_conv_desc.w_frag, engine_core.WeightStore.frag3) does the same
