@@ -7,7 +7,7 @@ from bench import build_model
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 out = sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/conv_tune_gfx950.json'
 share = len(sys.argv) > 4 and sys.argv[4] == 'share'
-eng, _ = build_model('cuda:0', R, 32, share_encoder=share)
+eng, _ = build_model('cuda:0', R, int(os.environ.get('GA_TUNE_REP', '32')), share_encoder=share)
 eng.x_in.uniform_()
 for e in eng.eps: e.normal_()
 eng.forward(); eng.dlogits.normal_(); eng.backward(); torch.cuda.synchronize()
