@@ -48,7 +48,7 @@ def robust_accuracy_delta(device='cuda:0', n_images=512, eot=4, steps=6, eps=8.0
                  precision=precision, share_encoder=False)
     g = torch.Generator().manual_seed(seed)
     t_cpu = t_gpu = 0.0
-    keep = {'hip': [], 'cpu': [], 'clean_agree': []}
+    keep = {'hip': [], 'cpu': [], 'clean_agree': [], 'cpu_on_hip': [], 'hip_on_cpu': []}
 
     dummy_noise = torch.ones(rows, *RES)          # scaled by eps = 0 (abstract_models.py:132-138 divides by its norm: must not be 0)
 
@@ -103,12 +103,22 @@ def robust_accuracy_delta(device='cuda:0', n_images=512, eot=4, steps=6, eps=8.0
         t_cpu += time.time() - t
         keep['cpu'].append(mc.argmax(dim=1) == labels)
         keep['hip'].append(hip_logits(xh, ef).argmax(dim=1).cpu() == labels)
-    hip, cpu, clean = (torch.cat(keep[k]) for k in ('hip', 'cpu', 'clean_agree'))
+        # the two implementations as JUDGES of the same adversarial examples (same noise): this isolates the parity of purifier +
+        # classifier at the adversarial points from the divergence of two sign-gradient trajectories
+        t = time.time()
+        _, mx = cpu_logits(xh.cpu(), ef, False)
+        t_cpu += time.time() - t
+        keep['cpu_on_hip'].append(mx.argmax(dim=1) == labels)
+        keep['hip_on_cpu'].append(hip_logits(xc, ef).argmax(dim=1).cpu() == labels)
+    hip, cpu, clean, cpu_on_hip, hip_on_cpu = (torch.cat(keep[k]) for k in ('hip', 'cpu', 'clean_agree', 'cpu_on_hip', 'hip_on_cpu'))
     acc_h, acc_c = hip.float().mean().item(), cpu.float().mean().item()
     return {'images': n_images, 'eot': eot, 'pgd_steps': steps, 'eps': eps, 'step': step,
             'robust_acc_hip': acc_h, 'robust_acc_oracle': acc_c, 'delta': abs(acc_h - acc_c),
             'differing_verdicts': int((hip != cpu).sum()), 'clean_predictions_differing': int((~clean).sum()),
+            'oracle_acc_on_hip_examples': cpu_on_hip.float().mean().item(), 'hip_acc_on_oracle_examples': hip_on_cpu.float().mean().item(),
+            'same_input_verdicts_differing': int((cpu_on_hip != hip).sum()) + int((hip_on_cpu != cpu).sum()),
             'oracle_seconds': t_cpu, 'hip_seconds': t_gpu, 'cpu_threads': threads,
             'what': f'{n_images} images x EoT {eot}, PGD-Linf {steps} steps (eps 8/255, step 2/255) through the reduced NVAE + VGG defender, '
                     'identical latent noise per step in both implementations, labels = the oracle\'s clean prediction, each implementation '
-                    'on its own trajectory; verdict = final adversarial example still classified as its label'}
+                    'on its own trajectory; verdict = final adversarial example still classified as its label.  same_input_verdicts_differing: '
+                    'each implementation also judges the OTHER one\'s adversarial examples (2 x N verdict pairs on identical inputs and noise)'}

@@ -330,5 +330,9 @@ def test_robust_accuracy_delta_at_a_sample_size_that_resolves_it():
     r = robust_accuracy_delta(DEV, n_images=128, eot=4, steps=4, chunk_images=128)
     print('   robust accuracy: HIP %.4f oracle %.4f, %d differing verdicts of %d, %d clean predictions differ (oracle %.0f s)' % (
         r['robust_acc_hip'], r['robust_acc_oracle'], r['differing_verdicts'], r['images'], r['clean_predictions_differing'], r['oracle_seconds']))
+    print('   as judges of each other\'s adversarial examples: oracle on HIP\'s %.4f, HIP on the oracle\'s %.4f, %d of %d same-input verdicts differ' % (
+        r['oracle_acc_on_hip_examples'], r['hip_acc_on_oracle_examples'], r['same_input_verdicts_differing'], 2 * r['images']))
     assert r['clean_predictions_differing'] == 0
     assert r['differing_verdicts'] <= 1 and r['delta'] <= 1.0 / 128 + 1e-9
+    # on identical inputs and noise the two implementations must reach the same verdict (logits agree at 1e-5: only an exact tie could differ)
+    assert r['same_input_verdicts_differing'] == 0
