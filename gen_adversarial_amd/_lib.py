@@ -23,7 +23,7 @@ GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PR
 (GA_OP_CONV, GA_OP_DWCONV5, GA_OP_REDUCE, GA_OP_SE_EXCITE, GA_OP_SE_APPLY, GA_OP_BILINEAR_BWD, GA_OP_SAMPLER,
  GA_OP_DML, GA_OP_MAXPOOL, GA_OP_IMAGE_IO, GA_OP_AXPBY, GA_OP_BLUR, GA_OP_REP_SUM, GA_OP_INTERLEAVE2,
  GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR, GA_OP_PIXELNORM,
- GA_OP_LATENT_MIX, GA_OP_POOL_DENORM, GA_OP_ATTN, GA_OP_LAYERNORM, GA_OP_RESIZE2_CROP, GA_OP_DEC_CELL, GA_OP_AVAE) = range(1, 30)
+ GA_OP_LATENT_MIX, GA_OP_POOL_DENORM, GA_OP_ATTN, GA_OP_LAYERNORM, GA_OP_RESIZE2_CROP, GA_OP_DEC_CELL, GA_OP_AVAE, GA_OP_DEC_CELL_HALO) = range(1, 31)
 GA_AVAE_ADAIN, GA_AVAE_AVGPOOL, GA_AVAE_PIXELNORM, GA_AVAE_SAMPLE = 0, 1, 2, 3
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
@@ -188,6 +188,13 @@ class DecCellDesc(C.Structure):
                 ('N', i32), ('H', i32), ('W', i32), ('C', i32), ('Hd', i32), ('backward', i32), ('act_rep', i32), ('variant', i32)]
 
 
+class DecCellHaloDesc(C.Structure):
+    _fields_ = [('x', fp), ('w1_hi', fp), ('w1_lo', fp), ('b1', fp), ('wd', fp), ('wd_bwd', fp), ('bd', fp),
+                ('w2_hi', fp), ('w2_lo', fp), ('b2', fp), ('w1t_hi', fp), ('w1t_lo', fp), ('dout', fp), ('pro_scale', fp), ('pro_shift', fp),
+                ('addend', fp), ('addend2', fp), ('y', fp),
+                ('N', i32), ('H', i32), ('W', i32), ('Cin', i32), ('Cout', i32), ('Hd', i32), ('backward', i32), ('up', i32)]
+
+
 class AvaeDesc(C.Structure):
     _fields_ = [('x', fp), ('a', fp), ('b', fp), ('c', fp), ('s', fp), ('dy', fp), ('y', fp), ('y2', fp),
                 ('mode', i32), ('backward', i32), ('N', i32), ('P', i32), ('C', i32), ('k', i32), ('H', i32), ('W', i32),
@@ -199,7 +206,7 @@ class _OpUnion(C.Union):
                 ('bil', BilinearBwdDesc), ('smp', SamplerDesc), ('dml', DmlDesc), ('mp', MaxpoolDesc),
                 ('io', ImageIoDesc), ('ax', AxpbyDesc), ('blur', BlurDesc), ('rs', RepSumDesc), ('il', Interleave2Desc),
                 ('mp3', Maxpool3s2Desc), ('ap', AvgpoolActDesc), ('gc', GconvDesc), ('pr', PreluDesc), ('un', UnaryDesc), ('mo', ModoutDesc), ('ub', Up2BlurDesc), ('lm', LatentMixDesc),
-                ('pd', PoolDenormDesc), ('at', AttnDesc), ('ln', LayernormDesc), ('rc', Resize2CropDesc), ('dc', DecCellDesc), ('pn', PixelnormDesc), ('av', AvaeDesc)]
+                ('pd', PoolDenormDesc), ('at', AttnDesc), ('ln', LayernormDesc), ('rc', Resize2CropDesc), ('dc', DecCellDesc), ('pn', PixelnormDesc), ('av', AvaeDesc), ('dh', DecCellHaloDesc)]
 
 
 class Op(C.Structure):
@@ -210,7 +217,7 @@ _KIND_FIELD = {GA_OP_CONV: 'conv', GA_OP_DWCONV5: 'dw', GA_OP_REDUCE: 'red', GA_
                GA_OP_SE_APPLY: 'app', GA_OP_BILINEAR_BWD: 'bil', GA_OP_SAMPLER: 'smp', GA_OP_DML: 'dml',
                GA_OP_MAXPOOL: 'mp', GA_OP_IMAGE_IO: 'io', GA_OP_AXPBY: 'ax', GA_OP_BLUR: 'blur', GA_OP_REP_SUM: 'rs',
                GA_OP_INTERLEAVE2: 'il', GA_OP_MAXPOOL3S2: 'mp3', GA_OP_AVGPOOL_ACT: 'ap', GA_OP_GCONV: 'gc', GA_OP_PRELU: 'pr', GA_OP_UNARY: 'un', GA_OP_MODOUT: 'mo', GA_OP_UP2_BLUR: 'ub', GA_OP_PIXELNORM: 'pn',
-               GA_OP_LATENT_MIX: 'lm', GA_OP_POOL_DENORM: 'pd', GA_OP_ATTN: 'at', GA_OP_LAYERNORM: 'ln', GA_OP_RESIZE2_CROP: 'rc', GA_OP_DEC_CELL: 'dc', GA_OP_AVAE: 'av'}
+               GA_OP_LATENT_MIX: 'lm', GA_OP_POOL_DENORM: 'pd', GA_OP_ATTN: 'at', GA_OP_LAYERNORM: 'ln', GA_OP_RESIZE2_CROP: 'rc', GA_OP_DEC_CELL: 'dc', GA_OP_AVAE: 'av', GA_OP_DEC_CELL_HALO: 'dh'}
 _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_REDUCE, SeExciteDesc: GA_OP_SE_EXCITE,
               SeApplyDesc: GA_OP_SE_APPLY, BilinearBwdDesc: GA_OP_BILINEAR_BWD, SamplerDesc: GA_OP_SAMPLER,
               DmlDesc: GA_OP_DML, MaxpoolDesc: GA_OP_MAXPOOL, ImageIoDesc: GA_OP_IMAGE_IO, AxpbyDesc: GA_OP_AXPBY,
@@ -218,11 +225,11 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
               Maxpool3s2Desc: GA_OP_MAXPOOL3S2, AvgpoolActDesc: GA_OP_AVGPOOL_ACT, GconvDesc: GA_OP_GCONV,
               PreluDesc: GA_OP_PRELU, UnaryDesc: GA_OP_UNARY, ModoutDesc: GA_OP_MODOUT, Up2BlurDesc: GA_OP_UP2_BLUR,
               PixelnormDesc: GA_OP_PIXELNORM, LatentMixDesc: GA_OP_LATENT_MIX, PoolDenormDesc: GA_OP_POOL_DENORM,
-              AttnDesc: GA_OP_ATTN, LayernormDesc: GA_OP_LAYERNORM, Resize2CropDesc: GA_OP_RESIZE2_CROP, DecCellDesc: GA_OP_DEC_CELL, AvaeDesc: GA_OP_AVAE}
+              AttnDesc: GA_OP_ATTN, LayernormDesc: GA_OP_LAYERNORM, Resize2CropDesc: GA_OP_RESIZE2_CROP, DecCellDesc: GA_OP_DEC_CELL, AvaeDesc: GA_OP_AVAE, DecCellHaloDesc: GA_OP_DEC_CELL_HALO}
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_dec_cell_halo', 'ga_dec_cell_halo_supported', 'ga_dec_cell_halo_has_backward', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op', 'ga_debug_set_conv_row_limit']
 
 
@@ -238,7 +245,7 @@ def _load():
                  ('ga_maxpool3s2', Maxpool3s2Desc), ('ga_avgpool_act', AvgpoolActDesc), ('ga_gconv', GconvDesc), ('ga_prelu', PreluDesc),
                  ('ga_unary', UnaryDesc), ('ga_modout', ModoutDesc), ('ga_up2_blur', Up2BlurDesc),
                  ('ga_latent_mix', LatentMixDesc), ('ga_pool_denorm', PoolDenormDesc), ('ga_attn', AttnDesc),
-                 ('ga_layernorm', LayernormDesc), ('ga_resize2_crop', Resize2CropDesc), ('ga_dec_cell', DecCellDesc), ('ga_avae', AvaeDesc)):
+                 ('ga_layernorm', LayernormDesc), ('ga_resize2_crop', Resize2CropDesc), ('ga_dec_cell', DecCellDesc), ('ga_avae', AvaeDesc), ('ga_dec_cell_halo', DecCellHaloDesc)):
         f = getattr(lib, n)
         f.argtypes = [C.POINTER(d), C.c_void_p]
         f.restype = C.c_int
@@ -269,6 +276,10 @@ def _load():
     lib.ga_debug_set_conv_row_limit.restype = C.c_long
     lib.ga_dec_cell_supported.argtypes = [C.c_int] * 5
     lib.ga_dec_cell_supported.restype = C.c_int
+    lib.ga_dec_cell_halo_supported.argtypes = [C.c_int] * 5
+    lib.ga_dec_cell_halo_supported.restype = C.c_int
+    lib.ga_dec_cell_halo_has_backward.argtypes = []
+    lib.ga_dec_cell_halo_has_backward.restype = C.c_int
     lib.ga_debug_set_conv_row_limit.argtypes = [C.c_long]
     lib.ga_microbench_hbm_copy.argtypes = [fp, fp, C.c_long, C.c_void_p]
     lib.ga_microbench_hbm_copy.restype = C.c_int
@@ -305,7 +316,7 @@ _DIRECT = {ConvDesc: 'ga_conv2d', DwDesc: 'ga_dwconv5', ReduceDesc: 'ga_rowchan_
            Interleave2Desc: 'ga_interleave2', Maxpool3s2Desc: 'ga_maxpool3s2', AvgpoolActDesc: 'ga_avgpool_act',
            GconvDesc: 'ga_gconv', PreluDesc: 'ga_prelu', UnaryDesc: 'ga_unary', ModoutDesc: 'ga_modout', Up2BlurDesc: 'ga_up2_blur',
            LatentMixDesc: 'ga_latent_mix', PoolDenormDesc: 'ga_pool_denorm', AttnDesc: 'ga_attn', LayernormDesc: 'ga_layernorm',
-           Resize2CropDesc: 'ga_resize2_crop', DecCellDesc: 'ga_dec_cell', AvaeDesc: 'ga_avae'}
+           Resize2CropDesc: 'ga_resize2_crop', DecCellDesc: 'ga_dec_cell', AvaeDesc: 'ga_avae', DecCellHaloDesc: 'ga_dec_cell_halo'}
 
 
 def run(desc, stream: int = 0):

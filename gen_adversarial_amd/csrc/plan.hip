@@ -34,6 +34,7 @@ static int run_one(const ga_op& op, void* stream) {
         case GA_OP_RESIZE2_CROP: return ga_resize2_crop(&op.u.rc, stream);
         case GA_OP_DEC_CELL:     return ga_dec_cell(&op.u.dc, stream);
         case GA_OP_AVAE:         return ga_avae(&op.u.av, stream);
+        case GA_OP_DEC_CELL_HALO: return ga_dec_cell_halo(&op.u.dh, stream);
         case GA_OP_AXPBY:        return ga_axpby(op.u.ax.x, op.u.ax.y, op.u.ax.n, op.u.ax.alpha, op.u.ax.beta, stream);
         default:                 return GA_E_UNSUPPORTED;
     }

@@ -395,6 +395,29 @@ int ga_dec_cell(const ga_dec_cell_desc* d, void* stream);
 int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_dec_cell takes the shape */
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * The same residual branch for the FEW-CHANNEL cells whose images are larger than a workgroup (the post-processing cells of
+ * NVAE's decoder, architecture.py:139-186 as model.py:211-228 instantiates them: 32 channels at 64 x 64, 64 at 32 x 32): a workgroup
+ * owns an 8 x 16 pixel tile and recomputes the expand conv on the tile's halo; csrc/dec_cell_halo.hip.
+ *   forward  (backward = 0): y = t3 [N,H,W,C] as ga_dec_cell
+ *   backward (backward = 1): y = dx [N,H,W,C] = addend + addend2 + W1^T . dt1, dt1 as ga_dec_cell's backward (never stored);
+ *            w2 = W2^T [Hd][C] as there, w1t = W1^T [C][Hd] (the backward weight of the expand conv), addends optional.
+ * Cin == Cout in {32, 64}, Hd % 32 == 0, H % 8 == 0, W % 16 == 0 (ga_dec_cell_halo_supported); up must be 0. */
+typedef struct ga_dec_cell_halo_desc {
+    const float* x;
+    const void* w1_hi; const void* w1_lo; const float* b1;
+    const float* wd; const float* wd_bwd; const float* bd;
+    const void* w2_hi; const void* w2_lo; const float* b2;
+    const void* w1t_hi; const void* w1t_lo;
+    const float* dout; const float* pro_scale; const float* pro_shift;
+    const float* addend; const float* addend2;
+    float* y;
+    int N, H, W, Cin, Cout, Hd; int backward, up;
+} ga_dec_cell_halo_desc;
+int ga_dec_cell_halo(const ga_dec_cell_halo_desc* d, void* stream);
+int ga_dec_cell_halo_supported(int N, int H, int W, int C, int Hd);
+int ga_dec_cell_halo_has_backward(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Pieces of the A-VAE competitor purifier (src/defenses/competitors/a_vae; csrc/avae.hip), selected by `mode`:
  *   GA_AVAE_ADAIN     forward : u = lrelu_0.2(x + b[c] * a[n,p]);  y = c[n,c] * (u - mean_p u) * rstd + c[n,C+c];  y2 = stats [N,C,2]
  *                     backward: dy -> y = d/dx [N,P,C], y2 = (d gamma | d beta) [N,2C]; s = the forward's stats
@@ -525,7 +548,7 @@ enum ga_op_kind { GA_OP_CONV = 1, GA_OP_DWCONV5 = 2, GA_OP_REDUCE = 3, GA_OP_SE_
                   GA_OP_AVGPOOL_ACT = 16, GA_OP_GCONV = 17, GA_OP_PRELU = 18, GA_OP_UNARY = 19,
                   GA_OP_MODOUT = 20, GA_OP_UP2_BLUR = 21, GA_OP_PIXELNORM = 22, GA_OP_LATENT_MIX = 23,
                   GA_OP_POOL_DENORM = 24, GA_OP_ATTN = 25, GA_OP_LAYERNORM = 26, GA_OP_RESIZE2_CROP = 27, GA_OP_DEC_CELL = 28,
-                  GA_OP_AVAE = 29 };
+                  GA_OP_AVAE = 29, GA_OP_DEC_CELL_HALO = 30 };
 typedef struct ga_axpby_desc { const float* x; float* y; long n; float alpha, beta; } ga_axpby_desc;
 typedef struct ga_rep_sum_desc { const float* x; float* y; long rows, inner; int rep, accumulate; } ga_rep_sum_desc;
 typedef struct ga_op {
@@ -537,7 +560,7 @@ typedef struct ga_op {
         ga_axpby_desc ax; ga_blur_desc blur; ga_rep_sum_desc rs; ga_interleave2_desc il;
         ga_maxpool3s2_desc mp3; ga_avgpool_act_desc ap; ga_gconv_desc gc; ga_prelu_desc pr;
         ga_unary_desc un; ga_modout_desc mo; ga_up2_blur_desc ub; ga_latent_mix_desc lm; ga_pool_denorm_desc pd;
-        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc; ga_dec_cell_desc dc; ga_avae_desc av;
+        ga_attn_desc at; ga_layernorm_desc ln; ga_resize2_crop_desc rc; ga_dec_cell_desc dc; ga_avae_desc av; ga_dec_cell_halo_desc dh;
         struct { const float* x; float* y; long rows; int C; } pn;
     } u;
 } ga_op;
