@@ -46,7 +46,9 @@ def dec_cell_algorithmic_flops(plan):
     """2 * MACs of the contractions a fused decoder-cell launch stands for: forward both 1x1 convs, backward the transpose of
     the second one (the recomputed first conv is extra work, not algorithmic; the first one's transpose is its own ga_conv2d)"""
     from gen_adversarial_amd import _lib as L
-    return sum(2 * d.N * d.H * d.W * d.C * d.Hd * (1 if d.backward else 2) for d in plan.descs if isinstance(d, L.DecCellDesc))
+    return (sum(2 * d.N * d.H * d.W * d.C * d.Hd * (1 if d.backward else 2) for d in plan.descs if isinstance(d, L.DecCellDesc)) +
+            # the halo form also carries d x (3 contractions backward) — algorithmic flops only, the halo recompute is not counted
+            sum(2 * d.N * d.H * d.W * d.Cin * d.Hd * (3 if d.backward else 2) for d in plan.descs if isinstance(d, L.DecCellHaloDesc)))
 
 
 def conv_algorithmic_bytes(plan):
@@ -864,10 +866,10 @@ def main():
         # the second kernel family of the path: the fused decoder cells (ga_dec_cell), per-op HIP events of one chunk
         from gen_adversarial_amd import _lib as L
         cell_ms, cell_n = 0.0, 0
-        headline_fused = sum(isinstance(dsc, L.DecCellDesc) for plan in (eng.fwd, eng.bwd) for dsc in plan.descs)
+        headline_fused = sum(isinstance(dsc, (L.DecCellDesc, L.DecCellHaloDesc)) for plan in (eng.fwd, eng.bwd) for dsc in plan.descs)
         for plan in (eng.fwd, eng.bwd):
             for dsc, ms in zip(plan.descs, plan.profile(s)):
-                if isinstance(dsc, L.DecCellDesc):
+                if isinstance(dsc, (L.DecCellDesc, L.DecCellHaloDesc)):
                     cell_ms, cell_n = cell_ms + ms, cell_n + 1
         if cell_n:
             cfl = dec_cell_algorithmic_flops(eng.fwd) + dec_cell_algorithmic_flops(eng.bwd)
@@ -965,7 +967,7 @@ def main():
                         e = build_model(device, xc.shape[0] * args.eot, args.eot, seed=0, precision=args.precision, store=store)[0]
                     finally:
                         Engine.fuse_min_workgroups = gate
-                    n_fused = sum(isinstance(d_, L_.DecCellDesc) for pl in (e.fwd, e.bwd) for d_ in pl.descs)
+                    n_fused = sum(isinstance(d_, (L_.DecCellDesc, L_.DecCellHaloDesc)) for pl in (e.fwd, e.bwd) for d_ in pl.descs)
                     e.x_in.copy_(xc.to(device))
                     for b_, e_ in zip(e.eps, epsc):
                         b_.copy_(e_.to(device))

@@ -55,6 +55,19 @@ struct w_small {
 
 struct hc_geom { int tiles_x, tiles_per_img; };
 
+// -DGA_HC_TRACE (make hctrace -> libga_ops_hctrace.so, tools/dec_cell_halo_trace.py): shader-clock sums per phase, lane 0 of every
+// wave of workgroup 0; slot 15 = the whole kernel
+#ifdef GA_HC_TRACE
+__device__ unsigned long long ga_hc_trace_buf[4 * 16];
+#define HC_T0 unsigned long long tsum[16] = {}; unsigned long long tprev = __builtin_amdgcn_s_memtime(); const unsigned long long tstart = tprev;
+#define HC_T(i) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[i] += tn - tprev; tprev = tn; }
+#define HC_TEND { tsum[15] = __builtin_amdgcn_s_memtime() - tstart; if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { for (int i = 0; i < 16; ++i) ga_hc_trace_buf[(threadIdx.x >> 6) * 16 + i] = tsum[i]; } }
+#else
+#define HC_T0
+#define HC_T(i)
+#define HC_TEND
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 template <int C>
 __global__ void __launch_bounds__(256, 2) dec_cell_halo_fwd_kernel(const ga_dec_cell_halo_desc d, const hc_geom gm) {
@@ -269,6 +282,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
     const int nch = d.Hd / DC_CH;
     const size_t tap_o = (size_t)(tid < 200 ? (tid >> 3) : 0) * d.Hd + 4 * c4;
 
+    HC_T0
     WA wa, wq;
     WB wr;
     wa.issue(g1h, g1l, C, 0, tid);
@@ -348,11 +362,13 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
         }
     (void)live1;
 
-    // (b) / (d): this thread's two ring-1 strips (strip s: rows s % 12, columns 4 (s / 12) ..), (e): its tile strip
+    // (b) / (d): this thread's two ring-1 strips (strip s: row s / 5, columns 4 (s % 5) ..), (e): its tile strip (row s / 4).  The
+    // two strips that share a 16-lane LDS phase are HORIZONTAL neighbours (4 pixels = 640 B = 128 B mod 256 B: all 64 banks); vertical
+    // ones would be a whole plane row apart (24 pixels = 0 mod 256 B: an 8-way conflict on every window read)
     int s1[2];
     s1[0] = strip;
     s1[1] = strip + 32;                                                 // 60 strips: the last four thread groups have one
-    const int oy = strip & 7, ox = (strip >> 3) * SW;
+    const int oy = strip >> 2, ox = (strip & 3) * SW;
     const __bf16* w1h = W1h + lrow * WA::PITCH + 8 * lh;
     const __bf16* w1l = W1l + lrow * WA::PITCH + 8 * lh;
     const __bf16* w2h = W2h + lrow * WA::PITCH + 8 * lh;
@@ -360,6 +376,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
     const __bf16* w3h = W3h + lrow * WB::PITCH + 8 * lh;
     const __bf16* w3l = W3l + lrow * WB::PITCH + 8 * lh;
 
+    HC_T(0)
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int h0 = ch * DC_CH;
@@ -371,6 +388,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
             *reinterpret_cast<floatx4*>(wT + (tid >> 3) * DC_CH + 4 * c4) = tapsT;
         }
         __syncthreads();
+        HC_T(1)
         const float b1v = d.b1[h0 + lrow];
         const floatx4 bd4 = *reinterpret_cast<const floatx4*>(d.bd + h0 + 4 * c4);
         {
@@ -400,13 +418,15 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
                     if (p4i[i][r >> 2] >= 0) P4[p4i[i][r >> 2] + (r & 3) * DC_PS] = sg * (1.0f + v * (1.0f - sg));
                 }
         }
+        HC_T(2)
         __syncthreads();
+        HC_T(3)
         // ---- (b) SiLU'(t2c) on ring 1, in registers
         floatx4 g2[2][SW];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (s1[k] < 60) {
-                const int wy = s1[k] % HW1_H, wx0 = (s1[k] / HW1_H) * SW;
+                const int wy = s1[k] / 5, wx0 = (s1[k] % 5) * SW;
                 dw_strip<SW>(g2[k], PA + (wy * HW2_W + wx0) * DC_PS + 4 * c4, wS + 4 * c4, HW2_W);
 #pragma unroll
                 for (int j = 0; j < SW; ++j) {
@@ -416,6 +436,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
                 }
             }
         }
+        HC_T(4)
         // ---- (c) g = dt3 . W2c^T on ring 1
         floatx16 gg[2];
 #pragma unroll
@@ -423,18 +444,22 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
 #pragma unroll
             for (int r = 0; r < 16; ++r) gg[i][r] = 0.f;
         gemm_resident<2, KS>(gg, gh, gl, w2h, w2l);
+        HC_T(5)
         __syncthreads();                // every strip is done reading SiLU(t1c)
+        HC_T(6)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (pa1[i][r >> 2] >= 0) PA[pa1[i][r >> 2] + (r & 3) * DC_PS] = gg[i][r];
+        HC_T(7)
         __syncthreads();
+        HC_T(8)
         // ---- (d) dt2c = g * SiLU'(t2c), each thread on its own strips
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (s1[k] < 60) {
-                const int wy = s1[k] % HW1_H, wx0 = (s1[k] / HW1_H) * SW;
+                const int wy = s1[k] / 5, wx0 = (s1[k] % 5) * SW;
 #pragma unroll
                 for (int j = 0; j < SW; ++j) {
                     floatx4* q = reinterpret_cast<floatx4*>(PA + ((wy + 2) * HW2_W + wx0 + j + 2) * DC_PS + 4 * c4);
@@ -442,7 +467,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
                 }
             }
         }
+        HC_T(9)
         __syncthreads();
+        HC_T(10)
         // ---- (e) dt1c = dw5^T(dt2c) * SiLU'(t1c) on the tile -> split planes
         {
             floatx4 a[SW];
@@ -457,7 +484,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
                 *reinterpret_cast<bf16x4*>(P2l + ip * DC_LDB + 4 * c4) = lo;
             }
         }
+        HC_T(11)
         __syncthreads();
+        HC_T(12)
         // ---- (f) dx += dt1c . W1c
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -473,7 +502,9 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
             }
         }
+        HC_T(13)
         __syncthreads();                // planes, weight buffers and taps are rewritten by the next chunk
+        HC_T(14)
     }
     // ---- dx = addend + addend2 + acc
 #pragma unroll
@@ -487,6 +518,7 @@ __global__ void __launch_bounds__(256, 1) dec_cell_halo_bwd_kernel(const ga_dec_
             if (d.addend2) v += d.addend2[o];
             d.y[o] = v;
         }
+    HC_TEND
 }
 
 static size_t hc_lds_bwd(int C) {
@@ -504,6 +536,12 @@ static int launch_hc_bwd(const ga_dec_cell_halo_desc& d, const hc_geom& gm, hipS
 }
 
 }  // namespace ga
+
+#ifdef GA_HC_TRACE
+extern "C" int ga_hc_trace_read(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ga::ga_hc_trace_buf), (size_t)n * 8) == hipSuccess ? GA_OK : GA_E_LAUNCH;
+}
+#endif
 
 extern "C" int ga_dec_cell_halo_supported(int N, int H, int W, int C, int Hd) {
     if (N <= 0 || (C != 32 && C != 64) || Hd <= 0 || Hd % 32) return 0;

@@ -44,6 +44,10 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
     # 256, whatever the row count up to 256 workgroups), the three unfused launches scale with the rows: below ~160 workgroups they win
     # (the reference protocol of one image x EoT 32 would pay 10 ms of a 21 ms step).  GA_FUSE_DEC_CELL=force: always (tests).
     fuse_min_workgroups = 0 if os.environ.get('GA_FUSE_DEC_CELL') == 'force' else 160
+    # ga_dec_cell_halo (8 x 16 tiles with a recomputed halo for the few-channel post-processing cells): parity-green, forward 0.63 vs
+    # 0.95 ms and 0.32 vs 0.57 ms per 512-row chunk, but its backward needs a two-pixel-deeper halo — 2.9x the depthwise work, LDS-bound —
+    # and measures 2.44 vs 1.22 ms / 1.29 vs 0.63 ms: OFF unless GA_FUSE_HALO_CELL=1
+    fuse_halo_cells = os.environ.get('GA_FUSE_HALO_CELL', '0') == '1'
     # ga_dec_cell variant for the 128-channel cells: 0 = four waves per workgroup, 1 = eight (two per SIMD); same results
     dec_cell_variant = int(os.environ.get('GA_DEC_CELL_VARIANT', '1'))
 

@@ -80,8 +80,26 @@ class NvaeBuilder:
         fused = (not up and not nd and self.precision == 'bf16x3' and self.fuse_dec_cells and cell.cout == x.c
                  and L.lib.ga_dec_cell_supported(n, H, W, x.c, hid_c) == 1
                  and n * H * W // (256 if x.c == 128 else 128) >= self.fuse_min_workgroups)
+        # few-channel cells on images larger than a workgroup (post-processing): 8 x 16 tiles with a recomputed halo, and d x from
+        # the same launch (ga_dec_cell_halo); one cotangent per forward row only
+        halo = (not fused and not up and not nd and self.precision == 'bf16x3' and self.fuse_dec_cells and self.fuse_halo_cells and cell.cout == x.c
+                and self.cot_rep == 1 and L.lib.ga_dec_cell_halo_supported(n, H, W, x.c, hid_c) == 1
+                and n * H * W // 128 >= self.fuse_min_workgroups)
         t3 = Act(self, n, H, W, cell.cout, p + '.t3')
         out = Act(self, n, H, W, cell.cout, p + '.out')
+
+        def halo_desc(backward: int) -> L.DecCellHaloDesc:
+            f = L.DecCellHaloDesc()
+            f.x, f.b1, f.wd, f.wd_bwd, f.bd, f.b2 = (_ptr(x.t), _ptr(wts['b1']), _ptr(wts['wd']), _ptr(wts['wd_bwd']),
+                                                    _ptr(wts['bd']), _ptr(wts['b2']))
+            if not self.dry_run:
+                (h1, l1), (h2, l2) = self.store.split(wts['w1']), self.store.split(wts['w2_bwd' if backward else 'w2'])
+                f.w1_hi, f.w1_lo, f.w2_hi, f.w2_lo = _ptr(h1), _ptr(l1), _ptr(h2), _ptr(l2)
+                if backward:
+                    h3, l3 = self.store.split(wts['w1_bwd'])
+                    f.w1t_hi, f.w1t_lo = _ptr(h3), _ptr(l3)
+            f.N, f.H, f.W, f.Cin, f.Cout, f.Hd, f.backward, f.up = n, H, W, x.c, cell.cout, hid_c, backward, 0
+            return f
 
         def fused_desc(backward: int) -> L.DecCellDesc:
             f = L.DecCellDesc()
@@ -96,6 +114,10 @@ class NvaeBuilder:
 
         if fused:
             f = fused_desc(0)
+            f.y = _ptr(t3.t)
+            self.fwd.add(f, p + '.cell')
+        elif halo:
+            f = halo_desc(0)
             f.y = _ptr(t3.t)
             self.fwd.add(f, p + '.cell')
         else:
@@ -129,6 +151,14 @@ class NvaeBuilder:
         def backward():
             nc = out.g.shape[0]                                 # cotangent rows: n * cot_rep
             ps, pb = self.se_backward(p, out.g, t3, wts, gate, hid, H * W, res_scale=rs)
+            if halo:            # d x = out.g (identity skip) [+ what is already in x.g] + W1^T dt1, dt1 never stored
+                b = halo_desc(1)
+                b.dout, b.pro_scale, b.pro_shift, b.addend, b.y = _ptr(out.g), _ptr(ps), _ptr(pb), _ptr(out.g), _ptr(x.g)
+                if x.g_written:
+                    b.addend2 = _ptr(x.g)
+                self.bwd.add(b, p + '.cell^T')
+                x.g_written = True
+                return
             dt1 = self.scratch((nc, h, w, hid_c), 'dec_dt1')
             if fused:
                 b = fused_desc(1)

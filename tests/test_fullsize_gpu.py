@@ -225,6 +225,37 @@ def test_fused_decoder_cells_equal_the_unfused_launches_bitwise(model, monkeypat
     assert b1 < 0.75 * b0          # the two 6C-wide tensors of those cells are no longer stored
 
 
+def test_halo_fused_post_processing_cells_equal_the_unfused_launches(model, monkeypatch):
+    """ga_dec_cell_halo (off by default: its backward is slower than the launches it replaces) selected for the two
+    few-channel post-processing cells of a 32-row plan, against the default plan: the unfused 1x1 convs of these cells run on other
+    kernels (tile shapes, exact-fp32 for the tiny K), so equality is at rounding level, not bitwise."""
+    from gen_adversarial_amd import _lib as L
+    m, spec = model, model['spec']
+    rows, rep = 32, 4
+    gen = torch.Generator().manual_seed(23)
+    imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
+    dlog = torch.randn(rows, 100, generator=gen)
+    out = []
+    for halo in (False, True):
+        monkeypatch.setattr(Engine, 'fuse_halo_cells', halo)
+        eng = engine(m, rows, rep)
+        n_halo = sum(isinstance(d, L.DecCellHaloDesc) for pl in (eng.fwd, eng.bwd) for d in pl.descs)
+        assert n_halo == (4 if halo else 0), n_halo
+        fill(eng, imgs, eps)
+        eng.forward()
+        eng.dlogits.view(rows, -1).copy_(dlog.to(DEV))
+        eng.backward()
+        torch.cuda.synchronize()
+        out.append((eng.purified.clone(), eng.logits.clone(), eng.dx.clone()))
+        del eng
+        torch.cuda.empty_cache()
+    for a, b, what in zip(out[0], out[1], ('purified', 'logits', 'input gradient')):
+        e = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+        print(f'halo-fused vs unfused post-processing cells, {what}: {e:.2e}')
+        assert e < 2e-5, what
+
+
 def test_bench_shape_512_rows_fused_plan_vs_unfused_plan_and_oracle(model, monkeypatch):
     """The shape bench.py times (512-row chunk plans: 16 images x EoT 32): at 512 / 256 workgroups the engine
     selects ga_dec_cell for 32 cells per direction BY ITSELF.  (a) That plan against the same plan built from the unfused launches:
