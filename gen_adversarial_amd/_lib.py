@@ -229,7 +229,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_dec_cell_halo', 'ga_dec_cell_halo_supported', 'ga_dec_cell_halo_has_backward', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_dec_cell_halo', 'ga_dec_cell_halo_supported', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op', 'ga_debug_set_conv_row_limit']
 
 
@@ -278,8 +278,6 @@ def _load():
     lib.ga_dec_cell_supported.restype = C.c_int
     lib.ga_dec_cell_halo_supported.argtypes = [C.c_int] * 5
     lib.ga_dec_cell_halo_supported.restype = C.c_int
-    lib.ga_dec_cell_halo_has_backward.argtypes = []
-    lib.ga_dec_cell_halo_has_backward.restype = C.c_int
     lib.ga_debug_set_conv_row_limit.argtypes = [C.c_long]
     lib.ga_microbench_hbm_copy.argtypes = [fp, fp, C.c_long, C.c_void_p]
     lib.ga_microbench_hbm_copy.restype = C.c_int

@@ -550,8 +550,6 @@ extern "C" int ga_dec_cell_halo_supported(int N, int H, int W, int C, int Hd) {
     return 1;
 }
 
-extern "C" int ga_dec_cell_halo_has_backward(void) { return 1; }
-
 extern "C" int ga_dec_cell_halo(const ga_dec_cell_halo_desc* d, void* s) {
     ga::clear_stale_error();
     if (!d || !d->x || !d->w1_hi || !d->w1_lo || !d->b1 || !d->wd || !d->bd || !d->w2_hi || !d->w2_lo || !d->y) return GA_E_BADARG;

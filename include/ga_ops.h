@@ -415,7 +415,6 @@ typedef struct ga_dec_cell_halo_desc {
 } ga_dec_cell_halo_desc;
 int ga_dec_cell_halo(const ga_dec_cell_halo_desc* d, void* stream);
 int ga_dec_cell_halo_supported(int N, int H, int W, int C, int Hd);
-int ga_dec_cell_halo_has_backward(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Pieces of the A-VAE competitor purifier (src/defenses/competitors/a_vae; csrc/avae.hip), selected by `mode`:
