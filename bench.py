@@ -28,6 +28,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide, "Peak BF16/FP16 MFMA ~2.5 PF de
 # precision 'bf16x3': every fp32-class product costs 3 bf16 MFMAs (hi*hi + hi*lo + lo*hi), so the ceiling of the
 # ALGORITHMIC flop rate of the dominant kernel is a third of the dense bf16 peak.
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+PEAK_HBM_TBPS = 8.0                # same guide, "HBM3E peak BW 8.0 TB/s spec" (6.29 TB/s measured by its float4 copy)
 
 
 def conv_algorithmic_flops(plan):
@@ -63,6 +64,55 @@ def conv_algorithmic_bytes(plan):
             if d.addend:
                 total += 4 * d.Cout * (d.Ho * d.Wo if d.addend_bcast_n else pout // max(1, d.addend_rep))
     return total
+
+
+def hbm_bound_classes(eng, stream):
+    """BASELINE.md §3 / SURVEY.md §8(d): achieved_hbm = algorithmic bytes / kernel time / HBM peak for each memory-bound kernel class
+    of one chunk (forward + backward plan): per-op HIP-event durations (ga_plan_profile) and the bytes each op must move at least
+    once (its inputs and outputs, fp32; weights and per-row vectors are negligible and not counted)."""
+    from gen_adversarial_amd import _lib as L
+    acc = {}
+
+    def add(name, nbytes, ms):
+        e = acc.setdefault(name, [0.0, 0.0, 0])
+        e[0] += nbytes
+        e[1] += ms
+        e[2] += 1
+    for plan in (eng.fwd, eng.bwd):
+        for d, ms in zip(plan.descs, plan.profile(stream)):
+            if isinstance(d, L.DwDesc):
+                pout = d.N * d.H * d.W
+                pin = pout // 4 if (d.up2 or d.pool2) else pout
+                # forward: read x (low resolution when up2), write y; backward: read dy and the saved input, write dx
+                nb = 4 * d.C * ((pin + pout) if not d.dact_x else (pout + pin + (pin if d.pool2 else pout)))
+                add('dwconv5 (depthwise 5x5 + SiLU of the unfused decoder cells)', nb, ms)
+            elif isinstance(d, L.SeExciteDesc):
+                rows = d.N * d.P * d.C * 4
+                nb = rows * ((1 + (2 if d.out else 0)) if not d.backward else 2)      # t (+ skip, out) | t, dout
+                add('se_excite (squeeze + excite' + (', merge' if d.out else '') + (', backward' if d.backward else '') + ')', nb, ms)
+            elif isinstance(d, L.SeApplyDesc):
+                add('se_apply (out = skip + 0.1 gate t)', 3 * 4 * d.N * d.H * d.W * d.C, ms)
+            elif isinstance(d, L.SamplerDesc):
+                px = d.N * d.h * d.w
+                nb = 4 * px * ((d.ldq + (d.ldp if d.p else 0) + d.NL + d.ldz) if not d.backward else
+                               (d.ldz + d.ldq + (2 * d.ldp if d.p else 0) + d.NL + d.ldq))
+                add('sampler (soft clamp, exp, interpolation)' + (' backward' if d.backward else ''), nb, ms)
+            elif isinstance(d, L.DmlDesc):
+                px = d.N * d.H * d.W
+                nb = 4 * px * ((d.ld + 3 + d.ld_img) if not d.backward else (2 * d.ld + d.ld_img + 3))
+                add('dml_mean (mixture mean + clamp chain)' + (' backward' if d.backward else ''), nb, ms)
+            elif isinstance(d, L.ImageIoDesc):
+                add('image_io (EoT repeat, NCHW <-> NHWC)', 4 * d.N * d.H * d.W * (d.ld + 3), ms)
+            elif isinstance(d, L.AxpbyDesc):
+                add('axpby (gradient accumulation)', 4 * d.n * (3 if d.beta else 2), ms)
+            elif isinstance(d, L.MaxpoolDesc):
+                add('maxpool2 (VGG)', 4 * d.N * d.H * d.W * d.C * (1.25 if not d.backward else 1.5), ms)
+    out = {}
+    for name, (nb, ms, n) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        tbps = nb / (ms / 1e3) / 1e12 if ms > 0 else None
+        out[name] = {'launches_per_chunk': n, 'ms_per_chunk': ms, 'algorithmic_mb_per_chunk': nb / 1e6, 'achieved_tbps': tbps,
+                     'achieved_hbm': (tbps / PEAK_HBM_TBPS) if tbps else None}
+    return out
 
 
 ROCPROF = '/opt/rocm/bin/rocprofv3'
@@ -164,9 +214,13 @@ def measured_peaks(device):
         return e0.elapsed_time(e1) / 1e3 / reps
     t_copy = timed(lambda: L.check(L.lib.ga_microbench_hbm_copy(src.data_ptr(), dst.data_ptr(), n, st), 'hbm_copy'), 10)
     t_mfma = timed(lambda: L.check(L.lib.ga_microbench_mfma_bf16(out.data_ptr(), blocks, iters, st), 'mfma_bf16'), 5)
+    t_mfma16 = timed(lambda: L.check(L.lib.ga_microbench_mfma_bf16_shape(out.data_ptr(), blocks, iters, 16, st), 'mfma_bf16_16'), 5)
     flops = blocks * 4 * iters * 8 * 2 * 32 * 32 * 16
     del src, dst, out
     return {'hbm_copy_tbps': 2 * 4 * n / t_copy / 1e12, 'bf16_mfma_tflops': flops / t_mfma / 1e12,
+            # the other MFMA shape (the kernels use 32x32x16: the ceiling above stays the one they are normalised by).  Under the chip's
+            # power limit the 16x16x32 loop holds a higher clock; DESIGN.md §7 has what that is worth inside the conv kernel (2 - 7 %)
+            'bf16_mfma_tflops_16x16x32': flops / t_mfma16 / 1e12,
             'how': 'ga_microbench_hbm_copy (1 GiB float4 copy, read + write bytes / time) and ga_microbench_mfma_bf16 (bare '
                    '32x32x16 bf16 MFMA loop, pseudo-random operands, 512 workgroups x 4 waves x 160000 MFMAs), HIP events, this box'}
 
@@ -258,13 +312,13 @@ def Engine_clone(eng, model, device, args):
                   share_encoder=eng.share_encoder, store=eng.store)
 
 
-def clone_engine(eng, model, device, args):
+def clone_engine(eng, model, device, args, precision=None):
     """a second engine over the same folded weights (WeightStore) with its own activations, for another stream"""
     from gen_adversarial_amd.engine import Engine
     from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION
     sd, vsd, vspec, alphas = model
     return Engine(sd, ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, vsd, vspec, rows=eng.rows, rep=eng.rep, alphas=alphas,
-                  temperature=0.6, noise_eps=eng.noise_eps, device=device, precision=args.precision,
+                  temperature=0.6, noise_eps=eng.noise_eps, device=device, precision=precision or args.precision,
                   share_encoder=args.share_encoder, store=eng.store)
 
 
@@ -323,21 +377,25 @@ def secondary_measurements(out, args, device, model, store, x, labels):
     reference's own protocol (ONE image x EoT 32 per defender call: src/experiments/test_defense.py:116,60) eager and as HIP
     graphs, and BASELINE.json configs[2] (e4e + StyleGAN2-1024 + ResNet-50, 256 px, eps 4.0) with its own roofline block."""
     sec = out.setdefault('secondary', {})
-    # ---- exact fp32 (v_mfma_f32_32x32x2_f32) at the headline configuration: two chunks per step on one stream
+    # ---- exact fp32 (v_mfma_f32_32x32x2_f32) at the headline configuration: the same images, chunks and streams as `value`
     try:
-        log('secondary: fp32 precision ...')
-        e32, _ = build_model(device, args.chunk_rows, args.eot, seed=0, precision='fp32', share_encoder=False)
-        n_img = 2 * args.chunk_rows // args.eot
-        st = AttackStep([e32], [torch.cuda.Stream(device=device)], labels[:n_img].clone(), x[:n_img].clone())
+        log('secondary: fp32 precision at the headline configuration ...')
+        e32, m32 = build_model(device, args.chunk_rows, args.eot, seed=0, precision='fp32', share_encoder=False)
+        n_chunks = args.images * args.eot // args.chunk_rows
+        n_eng = max(1, min(args.streams, n_chunks))
+        engs = [e32] + [clone_engine(e32, m32, device, args, precision='fp32') for _ in range(n_eng - 1)]
+        st = AttackStep(engs, [torch.cuda.Stream(device=device) for _ in engs], labels.clone(), x.clone())
         t = _time_steps(st, 2, warm=1)
         f_ms, fc_ms, fn = e32.fwd.time(e32.stream(), iters=1, per_conv=True)
         b_ms, bc_ms, bn = e32.bwd.time(e32.stream(), iters=1, per_conv=True)
         fl = conv_algorithmic_flops(e32.fwd) + conv_algorithmic_flops(e32.bwd)
-        sec['fp32_precision'] = {'rows_per_s': 2 * args.chunk_rows / t, 'ms_per_step': t * 1e3, 'dtype': 'f32 (exact f32 MFMA)',
-                                 'what': f'{n_img} images x EoT {args.eot} per step ({args.chunk_rows}-row chunks, 1 stream), same workload as the headline',
+        sec['fp32_precision'] = {'rows_per_s': args.images * args.eot / t, 'ms_per_step': t * 1e3, 'dtype': 'f32 (exact f32 MFMA)',
+                                 'what': f'{args.images} images x EoT {args.eot} per step ({args.chunk_rows}-row chunks, {n_eng} streams): the headline '
+                                         'workload, images, chunking and streams with every contraction on v_mfma_f32_32x32x2_f32 (no fused decoder '
+                                         'cell and no tile 8 in this mode: their resident operands are split-bf16 fragments)',
                                  'roofline': {'bound': 'mfma', 'achieved': fl / ((fc_ms + bc_ms) / 1e3) / 1e12, 'peak': PEAK_FP32_MFMA_TFLOPS,
                                               'unit': 'TFLOP/s', 'frac': fl / ((fc_ms + bc_ms) / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}}
-        del st, e32
+        del st, e32, engs
         free_gpu_memory()
     except Exception as ex:
         sec['fp32_precision'] = {'rows_per_s': None, 'what': f'failed: {ex}'}
@@ -513,7 +571,7 @@ def trans_defender_measurement(args, device, rows=64, eot=32):
                         'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                         'launches_per_plan': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_plan': flops / 1e9, 'conv_ms_per_plan': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.defender_parity:
         from oracle import defender_oracle as D, trans_oracle as T          # the checker, never the thing measured
         tsd, tspec, gsd, gspec, avg, csd, cspec, alphas = parts
 
@@ -592,7 +650,7 @@ def e4e_defender_measurement(args, device, rows=64, chunk=32, eot=32):
                         'algorithmic_bytes_per_launch': (conv_algorithmic_bytes(eng.fwd) + conv_algorithmic_bytes(eng.bwd)) / (fn + bn),
                         'launches_per_chunk': int(fn + bn), 'avg_launch_ms': (fc_ms + bc_ms) / (fn + bn),
                         'algorithmic_gflop_per_chunk': flops / 1e9, 'conv_ms_per_chunk': fc_ms + bc_ms, 'plan_ms_fwd': f_ms, 'plan_ms_bwd': b_ms}}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.defender_parity:
         from oracle import defender_oracle as D                              # the checker, never the thing measured
         esd, espec, gsd, gspec, avg, csd, cspec, alphas = parts
 
@@ -692,11 +750,18 @@ def main():
     ap.add_argument('--pmc-workload', choices=['nvae', 'e4e', 'trans'], default='nvae', help='internal: which plans --pmc-child replays')
     ap.add_argument('--class-jacobian-batch', action='store_true',
                     help='secondary.class_jacobian: also time the 16-image batch (512 rows, K = 4), about a minute more')
-    ap.add_argument('--no-defender-pmc', action='store_true', help='skip the PMC passes over the configs[2] / configs[4] defender plans')
+    ap.add_argument('--defender-pmc', action='store_true',
+                    help='also run the PMC passes over the configs[2] / configs[4] defender plans (about 80 s more; off by default so that '
+                         'the default run stays inside 4 minutes: profiles/ holds the figures of a run with it)')
+    ap.add_argument('--defender-parity', action='store_true',
+                    help='secondary configs[2] / configs[4]: also run the CPU oracle on row 0 of the timed plans (about 40 s more; the same '
+                         'comparison, on more rows and with gradients, is tests/test_fullsize_configs_gpu.py)')
     ap.add_argument('--no-pmc', action='store_true', help='skip the two rocprofv3 --pmc passes (roofline.traffic = null)')
     ap.add_argument('--pmc-timeout', type=int, default=240)
-    ap.add_argument('--robust-acc-images', type=int, default=512,
-                    help='images of the robust-accuracy delta measurement beside the cpu baseline (0: skip; multiples of 128)')
+    ap.add_argument('--robust-acc-images', type=int, default=256,
+                    help='images of the robust-accuracy delta measurement beside the cpu baseline (0: skip; multiples of 64): the '
+                         'reference\'s APGD-CE at a fixed L2 bound, HIP vs oracle, paired 95 %% interval (tests/robust_acc_attack.py; '
+                         'profiles/ holds a 4096-image run of tools/robust_acc_delta.py apgd)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip every secondary measurement (rows256, shared encoder, fp32, reference protocol, e4e defender)')
     ap.add_argument('--stub-engine', action='store_true',
@@ -721,7 +786,7 @@ def main():
         log('PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one chunk replay in a child process) ...')
         pmc_bytes, pmc_note = measure_pmc_traffic(args)           # before this process initialises the GPU
         log(f'PMC: {pmc_bytes} bytes per conv launch ({pmc_note[:80]})')
-        if not args.no_secondary and not args.no_defender_pmc:
+        if not args.no_secondary and args.defender_pmc:
             for w in ('e4e', 'trans'):
                 args.defender_pmc[w] = measure_pmc_traffic(args, w)
                 log(f'PMC ({w} defender): {args.defender_pmc[w][0]} bytes per conv launch')
@@ -881,6 +946,12 @@ def main():
                 'bound': 'vector ALU + LDS of one wave per SIMD (two quarter-rate transcendentals per SiLU, 25 FMAs and 2.7 LDS reads per '
                          'depthwise output); the contractions are 25 % of its clocks (tools/dec_cell_trace.py)',
                 'share_of_plan_ms': cell_ms / (f_ms + b_ms)}
+        try:
+            out['hbm_bound_kernel_classes'] = dict(
+                hbm_bound_classes(eng, s), _note='BASELINE.md §3: achieved_hbm = algorithmic bytes (inputs + outputs of the op, fp32) / '
+                'HIP-event kernel time / 8 TB/s, per memory-bound kernel class of one 512-row chunk (forward + backward plan, one stream)')
+        except Exception as ex:
+            out['hbm_bound_kernel_classes'] = {'_note': f'failed: {type(ex).__name__}: {ex}'}
         if world == 1 and not args.no_secondary and not args.stub_engine:
             # BASELINE.json configs[3] names "PGD-40 + BPDA": the same 8192-row step with the purifier's Jacobian replaced by the
             # identity in the backward pass (forward through purifier + classifier, backward through the classifier alone)
@@ -990,15 +1061,16 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)
                 log('cpu baseline done')
                 if args.robust_acc_images > 0:
-                    # robust-accuracy delta HIP vs oracle at a sample size that resolves 0.2 % (the oracle as the checker, on a
-                    # reduced model it can run hundreds of images x PGD steps of: tests/robust_acc.py)
-                    log(f'robust-accuracy delta on {args.robust_acc_images} images (oracle on the host cores) ...')
+                    # robust accuracy under the reference's APGD-CE, HIP vs oracle, every draw pinned, with the paired 95 % interval of
+                    # the difference (the oracle as the checker, on a reduced model it can run hundreds of attacks on:
+                    # tests/robust_acc_attack.py; VERDICT r03 "next round" #3)
+                    log(f'robust accuracy under APGD-CE on {args.robust_acc_images} images (oracle on the host cores) ...')
                     try:
                         sys.path.insert(0, os.path.join(ROOT, 'tests'))
-                        from robust_acc import robust_accuracy_delta
+                        from robust_acc_attack import robust_accuracy_under_attack
                         free_gpu_memory()
-                        out['robust_accuracy_delta'] = robust_accuracy_delta(device, n_images=args.robust_acc_images, eot=4, steps=6,
-                                                                             precision=args.precision)
+                        out['robust_accuracy_delta'] = robust_accuracy_under_attack(device, n_images=args.robust_acc_images, eot=2, n_iter=5,
+                                                                                    bound=2.0, chunk_images=min(64, args.robust_acc_images))
                     except Exception as ex:
                         out['robust_accuracy_delta'] = {'delta': None, 'what': f'failed: {type(ex).__name__}: {ex}'}
                     log('robust-accuracy delta done')

@@ -25,6 +25,7 @@ GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PR
  GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR, GA_OP_PIXELNORM,
  GA_OP_LATENT_MIX, GA_OP_POOL_DENORM, GA_OP_ATTN, GA_OP_LAYERNORM, GA_OP_RESIZE2_CROP, GA_OP_DEC_CELL, GA_OP_AVAE, GA_OP_DEC_CELL_HALO) = range(1, 31)
 GA_AVAE_ADAIN, GA_AVAE_AVGPOOL, GA_AVAE_PIXELNORM, GA_AVAE_SAMPLE = 0, 1, 2, 3
+ABI_VERSION = 4     # include/ga_ops.h: GA_ABI_VERSION (descriptor layouts + entry points); _load() refuses any other library
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -229,7 +230,7 @@ _DESC_KIND = {ConvDesc: GA_OP_CONV, DwDesc: GA_OP_DWCONV5, ReduceDesc: GA_OP_RED
 
 EXPORTS = ['ga_conv2d', 'ga_dwconv5', 'ga_rowchan_reduce', 'ga_se_excite', 'ga_se_apply', 'ga_bilinear_up2_bwd',
            'ga_sampler_mix', 'ga_dml_mean', 'ga_maxpool2', 'ga_image_io', 'ga_axpby', 'ga_plan_run', 'ga_plan_time',
-           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_dec_cell_halo', 'ga_dec_cell_halo_supported', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
+           'ga_plan_profile', 'ga_split_bf16', 'ga_gauss_blur', 'ga_rep_sum', 'ga_interleave2', 'ga_maxpool3s2', 'ga_avgpool_act', 'ga_gconv', 'ga_prelu', 'ga_unary', 'ga_modout', 'ga_up2_blur', 'ga_pixelnorm', 'ga_latent_mix', 'ga_pool_denorm', 'ga_attn', 'ga_layernorm', 'ga_resize2_crop', 'ga_dec_cell', 'ga_dec_cell_supported', 'ga_dec_cell_halo', 'ga_dec_cell_halo_supported', 'ga_avae', 'ga_microbench_hbm_copy', 'ga_microbench_mfma_bf16', 'ga_microbench_mfma_bf16_shape', 'ga_graph_capture', 'ga_graph_launch', 'ga_graph_destroy',
            'ga_last_hip_error', 'ga_abi_version', 'ga_sizeof_op', 'ga_debug_set_conv_row_limit']
 
 
@@ -283,6 +284,11 @@ def _load():
     lib.ga_microbench_hbm_copy.restype = C.c_int
     lib.ga_microbench_mfma_bf16.argtypes = [fp, C.c_int, C.c_int, C.c_void_p]
     lib.ga_microbench_mfma_bf16.restype = C.c_int
+    lib.ga_microbench_mfma_bf16_shape.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.ga_microbench_mfma_bf16_shape.restype = C.c_int
+    if lib.ga_abi_version() != ABI_VERSION:
+        raise ImportError(f'ABI mismatch: {LIB_PATH} reports GA_ABI_VERSION {lib.ga_abi_version()}, the binding is written for '
+                          f'{ABI_VERSION}: rebuild with `make -C gen_adversarial_amd/csrc`')
     if lib.ga_sizeof_op() != C.sizeof(Op):
         raise ImportError(f'ABI mismatch: library ga_op is {lib.ga_sizeof_op()} bytes, binding is {C.sizeof(Op)}')
     return lib

@@ -68,49 +68,103 @@ __device__ __forceinline__ void epilogue1(const ga_conv_desc& d, const int m, co
 }
 
 
-// acc: per-wave TM x TN accumulator tiles in the 32x32 MFMA C/D layout; smem: >= BM*(BN+4) floats, free to overwrite
-template <int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&acc)[TM][TN], float* smem, const int m0,
+// The accumulators of one wave: TM x TN blocks of 32 x 32 outputs, held either as one v_mfma_f32_32x32x16 C/D tile each
+// (floatx16: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) or as 2 x 2 v_mfma_f32_16x16x32 tiles each
+// (floatx4 [2 TM][2 TN]: col = lane & 15, row = 4 (lane >> 4) + r).  acc_at() walks either form as (row, col, value) of the wave's
+// TM*32 x TN*32 sub-tile.
+template <int TM, int TN, class F>
+__device__ __forceinline__ void acc_walk(floatx16 (&acc)[TM][TN], const int lane, F&& f) {
+    const int lrow = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) f(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, j * 32 + lrow, acc[i][j][r]);
+}
+template <int TM2, int TN2, class F>
+__device__ __forceinline__ void acc_walk(floatx4 (&acc)[TM2][TN2], const int lane, F&& f) {
+    const int lc = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) f(i * 16 + 4 * lq + r, j * 16 + lc, acc[i][j][r]);
+}
+
+// acc: per-wave accumulators (either form above); smem: >= BM*(BN+4) floats, free to overwrite
+template <int WM, int WN, int TM, int TN, class ACC>
+__device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, float* smem, const int m0,
                                               const int n0, const int M, const int vec_out, const int splits, const int split) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDC = BN + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int lrow = lane & 31, lh = lane >> 5;
     const int HoWo = d.Ho * d.Wo;
     float* ws = splits > 1 ? d.ws + (size_t)split * M * d.Cout : nullptr;
     if (vec_out) {
         float* Cs = smem;                                   // [BM][LDC], the K loop's buffers are free now
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    Cs[(wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * TN * 32 + j * 32 + lrow] = acc[i][j][r];
-        __syncthreads();
         constexpr int QL = BN / 4;                          // channel-quads per row
         constexpr int ROWS = 256 / QL;                      // rows per pass
+        constexpr int NB = (BM / ROWS) < 4 ? (BM / ROWS) : 4;      // rows handled together: loads first, math after
+        constexpr int NIT = BM / (ROWS * NB);               // batches of NB rows per thread
+        static_assert(NIT * ROWS * NB == BM, "whole batches");
         const int q = tid % QL, rr = tid / QL;
         const int co = n0 + 4 * q;
-        if (co < d.Cout) {
-            constexpr int NB = (BM / ROWS) < 4 ? (BM / ROWS) : 4;      // rows handled together: loads first, math after
-            floatx4 bias4 = {0.f, 0.f, 0.f, 0.f}, ds4 = {1.f, 1.f, 1.f, 1.f}, dt4 = {0.f, 0.f, 0.f, 0.f};
-            if (!ws) {
-                if (d.bias) bias4 = *reinterpret_cast<const floatx4*>(d.bias + co);
-                if (d.dact_x && d.dact_scale) {
-                    ds4 = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
-                    dt4 = *reinterpret_cast<const floatx4*>(d.dact_shift + co);
+        const bool mine = co < d.Cout;
+        // The epilogue's global operands (act' input, addends) of batch b + 1 are requested BEFORE the arithmetic and the stores of
+        // batch b, and those of batch 0 before the accumulators go through LDS: one exposed memory round trip per workgroup instead
+        // of one per batch (r04; the loads of a batch used to be issued only after the previous batch's stores).  Two register sets,
+        // statically indexed (the batch loop is unrolled).  In-place accumulation (addend == y) is safe: a thread reads and writes
+        // the SAME elements, and each element belongs to one thread.
+        floatx4 u[2][NB], a1[2][NB], a2[2][NB];
+        auto issue = [&](const int set, const int rb0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int r = rb0 + k * ROWS;
+                const bool ok = m0 + r < M;
+                if (d.dact_x) {
+                    const size_t m = ok ? dact_row(d, (size_t)(m0 + r), HoWo) : 0;
+                    u[set][k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
+                }
+                if (d.addend) {
+                    size_t m = ok ? (size_t)(m0 + r) : 0;
+                    if (d.addend_bcast_n) m = m % HoWo;
+                    if (d.addend_rep > 1) m = ((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
+                    a1[set][k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
+                }
+                if (d.addend2) {
+                    const size_t m = ok ? (size_t)(m0 + r) : 0;
+                    a2[set][k] = *reinterpret_cast<const floatx4*>(d.addend2 + m * d.ldadd2 + co);
                 }
             }
-            for (int rb0 = rr; rb0 < BM; rb0 += ROWS * NB) {
-                floatx4 v[NB], u[NB], a1[NB], a2[NB];
+        };
+        floatx4 bias4 = {0.f, 0.f, 0.f, 0.f}, ds4 = {1.f, 1.f, 1.f, 1.f}, dt4 = {0.f, 0.f, 0.f, 0.f};
+        if (mine && !ws) {
+            if (d.bias) bias4 = *reinterpret_cast<const floatx4*>(d.bias + co);
+            if (d.dact_x && d.dact_scale) {
+                ds4 = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
+                dt4 = *reinterpret_cast<const floatx4*>(d.dact_shift + co);
+            }
+            issue(0, rr);
+        }
+        acc_walk(acc, lane, [&](const int row, const int col, const float v) {
+            Cs[(wm * TM * 32 + row) * LDC + wn * TN * 32 + col] = v;
+        });
+        __syncthreads();
+        if (mine) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rb0 = rr + it * ROWS * NB, set = it & 1;
+                floatx4 v[NB];
                 bool ok[NB];
+                if (!ws && it + 1 < NIT) issue(set ^ 1, rb0 + ROWS * NB);
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     const int r = rb0 + k * ROWS;
-                    ok[k] = (r < BM) && (m0 + r < M);
-                    v[k] = *reinterpret_cast<const floatx4*>(Cs + (r < BM ? r : 0) * LDC + 4 * q);
+                    ok[k] = m0 + r < M;
+                    v[k] = *reinterpret_cast<const floatx4*>(Cs + r * LDC + 4 * q);
                 }
                 if (ws) {
 #pragma unroll
@@ -118,39 +172,16 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                         if (ok[k]) *reinterpret_cast<floatx4*>(ws + (size_t)(m0 + rb0 + k * ROWS) * d.Cout + co) = v[k];
                     continue;
                 }
-                if (d.dact_x) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        const size_t m = ok[k] ? dact_row(d, (size_t)(m0 + rb0 + k * ROWS), HoWo) : 0;
-                        u[k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
-                    }
-                }
-                if (d.addend) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
-                        if (d.addend_bcast_n) m = m % HoWo;
-                        if (d.addend_rep > 1) m = ((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
-                        a1[k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
-                    }
-                }
-                if (d.addend2) {
-#pragma unroll
-                    for (int k = 0; k < NB; ++k) {
-                        const size_t m = ok[k] ? (size_t)(m0 + rb0 + k * ROWS) : 0;
-                        a2[k] = *reinterpret_cast<const floatx4*>(d.addend2 + m * d.ldadd2 + co);
-                    }
-                }
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     floatx4 o = v[k] + bias4;
                     const bool pre = (d.flags & GA_CONV_ADDEND_PRE_DACT) != 0;
-                    if (pre && d.addend) o += a1[k];
+                    if (pre && d.addend) o += a1[set][k];
                     if (d.dact_x && (d.flags & GA_CONV_DACT_PRELU)) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] *= u[k][e] > 0.f ? 1.f : ds4[e];
+                        for (int e = 0; e < 4; ++e) o[e] *= u[set][k][e] > 0.f ? 1.f : ds4[e];
                     } else if (d.dact_x) {
-                        const floatx4 uu = u[k] * ds4 + dt4;
+                        const floatx4 uu = u[set][k] * ds4 + dt4;
                         if (d.dact_act == GA_ACT_SILU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { const float sg = fast_sigmoid(uu[e]); o[e] *= sg * (1.0f + uu[e] * (1.0f - sg)) * ds4[e]; }
@@ -162,32 +193,24 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, floatx16 (&
                     if (d.addend && !pre) {
                         if (d.flags & GA_CONV_ADDEND_RELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] += fmaxf(a1[k][e], 0.f);
+                            for (int e = 0; e < 4; ++e) o[e] += fmaxf(a1[set][k][e], 0.f);
                         } else {
-                            o += a1[k];
+                            o += a1[set][k];
                         }
                     }
-                    if (d.addend2) o += a2[k];
+                    if (d.addend2) o += a2[set][k];
                     if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)(m0 + rb0 + k * ROWS) * d.ldy + co) = o;
                 }
             }
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int co = n0 + wn * TN * 32 + j * 32 + lrow;
-            if (co >= d.Cout) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m >= M) continue;
-                    if (ws) ws[(size_t)m * d.Cout + co] = acc[i][j][r];
-                    else epilogue1(d, m, co, acc[i][j][r], HoWo);
-                }
+        acc_walk(acc, lane, [&](const int row, const int col, const float v) {
+            const int co = n0 + wn * TN * 32 + col, m = m0 + wm * TM * 32 + row;
+            if (co < d.Cout && m < M) {
+                if (ws) ws[(size_t)m * d.Cout + co] = v;
+                else epilogue1(d, m, co, v, HoWo);
             }
-        }
+        });
     }
 }
 

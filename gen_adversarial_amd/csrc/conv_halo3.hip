@@ -13,6 +13,7 @@
 // Wide images (Wo a multiple of 128: the 256^2 .. 1024^2 layers of the e4e encoder and the StyleGAN2 synthesis network): the
 // tile is a 128-pixel SEGMENT of one row and its window 3 x 130 pixels (3x the tile instead of 9x); 13 patch slots per thread
 // instead of 9, hence a second set of instantiations (template parameter RP).
+#include <type_traits>
 #include "ga_common.h"
 #include "conv_epilogue.h"
 
@@ -51,6 +52,7 @@ struct halo_geom {
     int TH, NI, PH, PW, P;      // rows per image in the tile, images per tile, patch rows / cols per image, patch pixels
     int TW, wide;               // tile width (= Wo, or 128 for a row segment of a wide image: wide = 1)
     int RS, IS;                 // row / image stride of a patch plane, in bf16 elements
+    int ldh;                    // pixel pitch of a patch plane, in bf16 elements (LDH; 48 for the 16x16x32 fragment reads of tile 8)
     fastdiv fd_howo, fd_wo, fd_phpw, fd_pw, fd_thwo, fd_tw, fd_is;
 };
 
@@ -338,11 +340,12 @@ static void launch_halo_inst(const ga_conv_desc& d, hipStream_t stream, dim3 gri
 // and the patch is double-buffered where it fits: ONE barrier per 32-channel chunk (9 taps, 216 MFMAs per wave) instead of nine.
 // Same operand split, k order and accumulation order as conv_halo3_kernel: bitwise the same results.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int AFF, int ACT, int RPMAX>
+template <int AFF, int ACT, int RPMAX, bool M16>
 __global__ void __launch_bounds__(256, 2)
 conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const int C, const int nkc, const int vec_out,
                      const halo_geom g, const int dbuf, const int tab_off) {
     constexpr int WM = 1, WN = 4, TM = 4, TN = 1, BM = 128, BN = 128;
+    const int LDHr = g.ldh;                                  // pixel pitch of the patch planes (uniform)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int plane = g.NI * g.IS;                           // bf16 elements of one patch plane (hi or lo)
     __bf16* Pbase = reinterpret_cast<__bf16*>(smem);         // buffer b: hi at b * 2 * plane, lo behind it
@@ -360,7 +363,9 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave;
     const int c4 = tid & 7;
-    const int lrow = lane & 31, lh = lane >> 5;
+    // fragment lane map: 32x32x16 -> row lane & 31, k octet lane >> 5 (of a 16-deep step); 16x16x32 -> row lane & 15, k octet
+    // lane >> 4 (of the 32-deep chunk)
+    const int lrow = M16 ? (lane & 15) : (lane & 31), lh = M16 ? (lane >> 4) : (lane >> 5);
 
     constexpr int INV = 0x7fffffff;
     const int HoWo = d.Ho * d.Wo;
@@ -386,7 +391,7 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
                 const int img = fd_div(pp, g.fd_phpw);
                 const int rem = pp - img * g.PH * g.PW;
                 const int py = fd_div(rem, g.fd_pw), px = rem - py * g.PW;
-                pl = (img * g.IS + py * g.RS + px * LDH + 4 * c4) >> 2;
+                pl = (img * g.IS + py * g.RS + px * LDHr + 4 * c4) >> 2;
                 const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
                 if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
             }
@@ -409,14 +414,23 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
     }
     // a thread's slot entries are read by itself only; the prologue table is read by everybody in the first finish_patch below
     if (AFF != 0) __syncthreads();
-    int fragA[TM];
+    // 16x16x32: M tiles 4..7 sit 64 tile pixels behind tiles 0..3 — whole rows or whole images further, i.e. at ONE uniform
+    // offset (`halfoff`): 4 address registers serve all 8 fragments
+    int fragA[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int o = i * 32 + lrow;
+    for (int i = 0; i < 4; ++i) {
+        const int o = i * (M16 ? 16 : 32) + lrow;
         const int img = fd_div(o, g.fd_thwo);
         const int rem = o - img * g.TH * g.TW;
         const int y = fd_div(rem, g.fd_tw), x = rem - y * g.TW;
-        fragA[i] = img * g.IS + y * g.RS + x * LDH + 8 * lh;
+        fragA[i] = img * g.IS + y * g.RS + x * LDHr + 8 * lh;
+    }
+    int halfoff = 0;
+    if (M16) {
+        const int img = fd_div(64, g.fd_thwo);
+        const int rem = 64 - img * g.TH * g.TW;
+        const int y = fd_div(rem, g.fd_tw), x = rem - y * g.TW;
+        halfoff = img * g.IS + y * g.RS + x * LDHr;
     }
 
     floatx4 rpat[RPMAX];
@@ -486,32 +500,62 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
         for (int q = 0; q < 4; ++q) b[q] = p[q * 64];
     };
 
-    floatx16 acc[TM][TN];
+    // accumulators: 4 tiles of 32 x 32 (floatx16), or 8 x 2 tiles of 16 x 16 (floatx4) — 64 registers either way
+    typedef typename std::conditional<M16, floatx4[8][2], floatx16[TM][TN]>::type acc_t;
+    acc_t acc;
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    }
 
-    // A fragments of group (tap, k step) = 8 ds_read_b128 feeding 12 MFMAs; two register sets: the reads of group g + 1 are issued
-    // BEFORE the MFMAs of group g (the waits the compiler inserts are then counted ones: lgkmcnt(8) instead of a drain), so that
-    // a wave's instruction stream is MFMAs back to back with its operand reads riding in the gaps
-    bf16x8 ahs[2][TM], als[2][TM];
-    auto load_A = [&](const int set, const int buf, const int off) __attribute__((always_inline)) {
+    // A fragments of a group = 8 ds_read_b128 feeding 12 MFMAs of 32 cycles (32x32x16: group = (tap, k step), 4 M tiles x hi | lo)
+    // or 24 MFMAs of 16 cycles (16x16x32: group = (tap, half of the 8 M tiles), the whole 32-deep chunk per read); two register
+    // sets: the reads of group g + 1 are issued BEFORE the MFMAs of group g (the waits the compiler inserts are then counted ones:
+    // lgkmcnt(8) instead of a drain), so that a wave's instruction stream is MFMAs back to back with its operand reads riding in
+    // the gaps
+    bf16x8 ahs[M16 ? 1 : 2][4], als[M16 ? 1 : 2][4];
+    auto load_A = [&](const int set, const int buf, const int off, const int half) __attribute__((always_inline)) {
         const __bf16* Ph = Pbase + buf * 2 * plane;
         const __bf16* Pl = Ph + plane;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            ahs[set][i] = *reinterpret_cast<const bf16x8*>(Ph + fragA[i] + off);
-            als[set][i] = *reinterpret_cast<const bf16x8*>(Pl + fragA[i] + off);
+        for (int i = 0; i < 4; ++i) {
+            ahs[set][i] = *reinterpret_cast<const bf16x8*>(Ph + fragA[i] + off + (M16 ? half * halfoff : 0));
+            als[set][i] = *reinterpret_cast<const bf16x8*>(Pl + fragA[i] + off + (M16 ? half * halfoff : 0));
         }
     };
-    auto mma_group = [&](const int set, const uintx4 bh4, const uintx4 bl4) __attribute__((always_inline)) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bh4), bl = __builtin_bit_cast(bf16x8, bl4);
+    // weight fragments of one tap in b[4]: 32x32x16 -> [k step][hi | lo]; 16x16x32 -> [16-channel half of the wave's 32][hi | lo]
+    auto mma_group = [&](const int set, const uintx4 (&b)[4], const int sel) __attribute__((always_inline)) {
+        if constexpr (M16) {
+            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, b[0]), bl0 = __builtin_bit_cast(bf16x8, b[1]);
+            const bf16x8 bh1 = __builtin_bit_cast(bf16x8, b[2]), bl1 = __builtin_bit_cast(bf16x8, b[3]);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(als[set][i], bh, acc[i][0], 0, 0, 0);
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bl, acc[i][0], 0, 0, 0);
-            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bh, acc[i][0], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                floatx4& c0 = acc[4 * sel + i][0];
+                floatx4& c1 = acc[4 * sel + i][1];
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(als[set][i], bh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(als[set][i], bh1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[set][i], bl0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[set][i], bl1, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[set][i], bh0, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[set][i], bh1, c1, 0, 0, 0);
+            }
+        } else {
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, b[2 * sel]), bl = __builtin_bit_cast(bf16x8, b[2 * sel + 1]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(als[set][i], bh, acc[i][0], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bl, acc[i][0], 0, 0, 0);
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahs[set][i], bh, acc[i][0], 0, 0, 0);
+            }
         }
     };
 
@@ -529,9 +573,59 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
     __syncthreads();
     GA_HSTAMP(2)
     int buf = 0;
-    const int rowskip = g.RS - 3 * LDH;
+    const int rowskip = g.RS - 3 * LDHr;
     for (int chunk = cb; chunk < ce; ++chunk) {
-        load_A(0, buf, 0);
+        load_A(0, buf, 0, 0);
+        if constexpr (M16) {
+            // 16x16x32: ONE fragment register set, refilled tile by tile: the 6 MFMAs of M tile i (3 per 16-channel half of the
+            // wave's outputs) are followed by the two reads of tile i of the NEXT group into the registers they have just consumed —
+            // 18 MFMAs (288 cycles) before their first use
+            const __bf16* Ph = Pbase + buf * 2 * plane;
+            const __bf16* Pl = Ph + plane;
+#pragma unroll
+            for (int gi = 0; gi < 18; ++gi) {
+                const int tap = gi >> 1, half = gi & 1;
+                if (half == 0) {
+                    const int ntap = tap == 8 ? 0 : tap + 1;
+                    const int nchunk = tap == 8 ? min(chunk + 1, ce - 1) : chunk;
+                    load_B(bnxt, nchunk, ntap);
+                }
+                const int nt2 = (gi + 1) >> 1;
+                const int noff = nt2 * LDHr + (nt2 / 3) * rowskip + ((gi + 1) & 1) * halfoff;
+                const bf16x8 bh0 = __builtin_bit_cast(bf16x8, bcur[0]), bl0 = __builtin_bit_cast(bf16x8, bcur[1]);
+                const bf16x8 bh1 = __builtin_bit_cast(bf16x8, bcur[2]), bl1 = __builtin_bit_cast(bf16x8, bcur[3]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    floatx4& c0 = acc[4 * half + i][0];
+                    floatx4& c1 = acc[4 * half + i][1];
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(als[0][i], bh0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(als[0][i], bh1, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[0][i], bl0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[0][i], bl1, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[0][i], bh0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahs[0][i], bh1, c1, 0, 0, 0);
+                    if (gi + 1 < 18) {
+                        ahs[0][i] = *reinterpret_cast<const bf16x8*>(Ph + fragA[i] + noff);
+                        als[0][i] = *reinterpret_cast<const bf16x8*>(Pl + fragA[i] + noff);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // (the global loads, when this group has them)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dbuf && gi == 9 && chunk + 1 < ce) {
+                    finish_patch(chunk + 1, buf ^ 1);
+                    if (chunk + 2 < ce) issue_patch(chunk + 2);
+                }
+                if (half == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bcur[q] = bnxt[q];
+                }
+            }
+        } else
 #pragma unroll
         for (int gi = 0; gi < 18; ++gi) {
             const int tap = gi >> 1, ks = gi & 1;
@@ -543,13 +637,13 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
             }
             if (gi + 1 < 18) {
                 const int nt2 = (gi + 1) >> 1;
-                const int noff = nt2 * LDH + (nt2 / 3) * rowskip + ((gi + 1) & 1) * 16;
-                load_A((gi + 1) & 1, buf, noff);
+                const int noff = nt2 * LDHr + (nt2 / 3) * rowskip + (M16 ? 0 : ((gi + 1) & 1) * 16);
+                load_A((gi + 1) & 1, buf, noff, (gi + 1) & 1);
             }
             __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);       // (the global loads, when this group has them)
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);       // next group's 8 fragment reads first ...
-            mma_group(gi & 1, bcur[2 * ks], bcur[2 * ks + 1]);
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);      // ... then this group's 12 MFMAs
+            mma_group(gi & 1, bcur, ks);
+            __builtin_amdgcn_sched_group_barrier(0x008, M16 ? 24 : 12, 0);      // ... then this group's MFMAs
             __builtin_amdgcn_sched_barrier(0);
             if (dbuf && gi == 9 && chunk + 1 < ce) {        // the next chunk's patch into the other buffer, behind the MFMAs
                 finish_patch(chunk + 1, buf ^ 1);
@@ -578,12 +672,12 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
     GA_HSTAMP(4)
 }
 
-template <int AFF, int ACT, int RP>
+template <int AFF, int ACT, int RP, bool M16>
 static void launch_halo_bd_inst(const ga_conv_desc& d, hipStream_t stream, dim3 grid, size_t lds, int tilesN, int M, int nkc, int vec_out,
                                 const halo_geom& g, int dbuf, int tab_off) {
     static dyn_lds_cache attr;
-    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_halo3_bd_kernel<AFF, ACT, RP>), lds);
-    hipLaunchKernelGGL((conv_halo3_bd_kernel<AFF, ACT, RP>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, nkc, vec_out, g, dbuf,
+    (void)ensure_dyn_lds(attr, reinterpret_cast<const void*>(&conv_halo3_bd_kernel<AFF, ACT, RP, M16>), lds);
+    hipLaunchKernelGGL((conv_halo3_bd_kernel<AFF, ACT, RP, M16>), grid, dim3(256), lds, stream, d, tilesN, M, d.C1, nkc, vec_out, g, dbuf,
                        tab_off);
 }
 
@@ -606,7 +700,8 @@ int conv_halo3_supports(const ga_conv_desc& d) {
     }
 }
 
-static int halo_geometry(const ga_conv_desc& d, const int BM, halo_geom& g) {
+static int halo_geometry(const ga_conv_desc& d, const int BM, halo_geom& g, const int ldh = LDH) {
+    g.ldh = ldh;
     const int HoWo = d.Ho * d.Wo;
     g.wide = d.Wo >= BM ? 1 : 0;
     g.TW = g.wide ? BM : d.Wo;
@@ -617,8 +712,8 @@ static int halo_geometry(const ga_conv_desc& d, const int BM, halo_geom& g) {
     g.P = g.NI * g.PH * g.PW;
     if (g.P > 13 * 32) return GA_E_UNSUPPORTED;
     auto pad_to = [](int bytes, int want_mod256) { return bytes + ((want_mod256 - bytes) % 256 + 256) % 256; };
-    const int rs_bytes = pad_to(g.PW * LDH * 2, (g.TW * LDH * 2) % 256);
-    const int is_bytes = pad_to(g.PH * rs_bytes, (g.TH * g.TW * LDH * 2) % 256);
+    const int rs_bytes = pad_to(g.PW * ldh * 2, (g.TW * ldh * 2) % 256);
+    const int is_bytes = pad_to(g.PH * rs_bytes, (g.TH * g.TW * ldh * 2) % 256);
     g.RS = rs_bytes / 2;
     g.IS = is_bytes / 2;
     g.fd_howo = make_fastdiv(HoWo);
@@ -669,13 +764,14 @@ static int launch_halo(const ga_conv_desc& d, hipStream_t stream, int vec_out, i
     return check_launch();
 }
 
-static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits) {
+template <bool M16>
+static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits, const int ldh) {
     constexpr int BM = 128, BN = 128;
     if (!d.w_frag || !aligned16(d.w_frag)) return GA_E_UNSUPPORTED;
     const int M = d.N * d.Ho * d.Wo;
     const int nkc = d.C1 / HK;
     halo_geom g;
-    { const int rc = halo_geometry(d, BM, g); if (rc != GA_OK) return rc; }
+    { const int rc = halo_geometry(d, BM, g, ldh); if (rc != GA_OK) return rc; }
     if (splits > nkc) return GA_E_UNSUPPORTED;
     const int tilesM = (M + BM - 1) / BM, tilesN = (d.Cout + BN - 1) / BN;
     const size_t patch = (size_t)2 * g.NI * g.IS * 2;                   // hi + lo planes of one buffer, bytes
@@ -690,8 +786,15 @@ static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
     const dim3 grid(tilesM * tilesN, splits);
-#define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf, tab_off)
+#define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9, M16>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf, tab_off)
     if (g.P > 9 * 32) return GA_E_UNSUPPORTED;                          // row-segment tiles of wide images: the LDS-staged kernel
+#ifdef GA_HALO_EXP_ONLY     // quick experiment builds (make hexp): two prologues only
+    switch (halo_mode(d)) {
+        case 0x00: GA_HBD(0, GA_ACT_NONE); break;
+        case 0x01: GA_HBD(0, GA_ACT_SILU); break;
+        default: return GA_E_UNSUPPORTED;
+    }
+#else
     switch (halo_mode(d)) {
         case 0x00: GA_HBD(0, GA_ACT_NONE); break;
         case 0x01: GA_HBD(0, GA_ACT_SILU); break;
@@ -703,6 +806,7 @@ static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out
         case 0x20: GA_HBD(2, GA_ACT_NONE); break;
         default: return GA_E_UNSUPPORTED;
     }
+#endif
 #undef GA_HBD
     return check_launch();
 }
@@ -711,10 +815,20 @@ static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out
 // global memory (needs w_frag); called by ga_conv2d after validation
 int conv_halo3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits) {
     switch (tile) {
-        case 8: return launch_halo_bd(d, stream, vec_out, splits);
+        case 8: return launch_halo_bd<false>(d, stream, vec_out, splits, LDH);
+#ifdef GA_HALO_EXP_ONLY
+        // experiment build only (make hexp, tools/conv_ab.py): the same kernel on v_mfma_f32_16x16x32_bf16 (M16), w_frag in the m16
+        // order (WeightStore.frag3(w, m16=True)); 9 = 80-B pixel pitch (2-way fragment reads), 10 = 96-B pitch (conflict-free).
+        // Measured r04 (gpurun_out/r04_ab_m16.log): the bare MFMA loop runs 15 % faster on this shape, the kernel
+        // 2 - 7 % (16x16x128: 111.4 -> 105.9 us, 8x8x256: 102.2 -> 100.3, 32x32x64: 213.8 -> 199.8) and 4 % SLOWER at 4x4x512
+        // (115.3 -> 120.3): not worth a second set of instantiations (+5 minutes of build) and a second weight copy — not shipped.
+        case 9: return launch_halo_bd<true>(d, stream, vec_out, splits, 40);
+        case 10: return launch_halo_bd<true>(d, stream, vec_out, splits, 48);
+#else
         case 5: return launch_halo<2, 2, 2, 2>(d, stream, vec_out, splits);
         case 6: return launch_halo<4, 1, 1, 2>(d, stream, vec_out, splits);
         case 7: return launch_halo<4, 1, 1, 1>(d, stream, vec_out, splits);
+#endif
         default: return GA_E_UNSUPPORTED;
     }
 }

@@ -545,7 +545,7 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
                      d.KH * d.KW <= 32 && k.x_bytes > 0 && k.w_bytes > 0 && (d.C2 == 0 || k.x2_bytes > 0) &&
                      aligned16(d.w_hi) && aligned16(d.w_lo) && conv_bf3_supports(d);
     int rc;
-    if (tile >= 5 && tile <= 8) {       // halo-staged 3x3 (explicit request only: the tune table names it per shape)
+    if (tile >= 5 && tile <= 10) {      // halo-staged 3x3 (explicit request only: the tune table names it per shape)
         if (!(bf3 && vec_out && conv_halo3_supports(d))) return GA_E_UNSUPPORTED;
         rc = conv_halo3_dispatch(k, stream, tile, vec_out, splits);
     } else if (bf3) {

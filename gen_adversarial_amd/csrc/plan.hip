@@ -155,5 +155,5 @@ extern "C" int ga_graph_destroy(void* graph) {
 }
 
 extern "C" const char* ga_last_hip_error(void) { return hipGetErrorString(ga::g_last_err); }
-extern "C" int ga_abi_version(void) { return 1; }
+extern "C" int ga_abi_version(void) { return GA_ABI_VERSION; }
 extern "C" unsigned long ga_sizeof_op(void) { return sizeof(ga_op); }

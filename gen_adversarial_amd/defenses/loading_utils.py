@@ -87,19 +87,15 @@ def load_Vgg11(path: str, device: str, n_classes: int = 100) -> VggWeights:
     ckpt = _torch_load(path)
     sd = ckpt['state_dict']
     width_div = 64 // sd['model.features.0.weight'].shape[0]
-    return VggWeights(sd, sd['model.classifier.3.weight'].shape[0] if n_classes is None else n_classes, width_div)
+    # the head in the checkpoint decides the class count (the reference builds Vgg(n_classes=100) and load_state_dict would refuse any
+    # other head; a checkpoint with another head is a test / user model, not an error here)
+    return VggWeights(sd, sd['model.classifier.3.weight'].shape[0], width_div)
 
 
 def load_NVAE(checkpoint_path: str, device: str, temperature: float) -> NVAEWeights:
     ckpt = _torch_load(checkpoint_path)
     config = ckpt['configuration']
     return NVAEWeights(ckpt[f'state_dict_temp={temperature}'], dict(config['autoencoder']), tuple(config['resolution']))
-
-
-def _next(name):
-    def fn(*a, **k):
-        raise NotImplementedError(f'{name}: not on the built path yet (SURVEY.md §8 rows a13-a18 are "next")')
-    return fn
 
 
 def load_ResNet50(path: str, device: str, n_classes: int = 2) -> ResNetWeights:

@@ -127,10 +127,21 @@ class _EngineOwner:
         self._store = WeightStore(dev)
         self._fixed_noise = None
 
-    def _engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1) -> Engine:
+    # owners whose _make_engine takes need_backward=False (the NVAE defender): calls that cannot be differentiated (torch.no_grad(),
+    # or an input that does not require grad: clean predictions, get_purified, the alpha-learning objective) run on a FORWARD-ONLY
+    # engine — no gradient buffers, and the post-processing decoder cells as ga_dec_cell_halo launches, whose forward kernel is
+    # faster than the launches it replaces while its backward is not; logits and purified image are bitwise those
+    # of the differentiable engine
+    supports_forward_only = False
+
+    def _engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1, forward_only: bool = False) -> Engine:
+        forward_only = forward_only and self.supports_forward_only and cot_rep == 1
         key = (rows, rep, with_noise) if cot_rep == 1 else (rows, rep, with_noise, cot_rep)
+        if forward_only:
+            key = key + ('forward_only',)
         if key not in self._engines:
-            self._engines[key] = (self._make_engine(rows, rep, with_noise) if cot_rep == 1 else
+            self._engines[key] = (self._make_engine(rows, rep, with_noise, need_backward=False) if forward_only else
+                                  self._make_engine(rows, rep, with_noise) if cot_rep == 1 else
                                   self._make_engine(rows, rep, with_noise, cot_rep=cot_rep))
         eng = self._engines[key]
         alphas = self._current_alphas()
@@ -143,21 +154,22 @@ class _EngineOwner:
 
     # noise handling -------------------------------------------------------------------------------------------
     def fixed_noise(self, eps: Optional[List[torch.Tensor]] = None, input_noise: Optional[torch.Tensor] = None):
-        """Use the given N(0,1) draws for the next calls instead of fresh ones (parity tests); None resets."""
+        """Use the given N(0,1) draws for the next calls instead of fresh ones (parity tests); None resets.  A pinned draw may hold
+        more rows than a call needs (attacks that drop finished images call with fewer rows): row r of a call uses draw r."""
         self._fixed_noise = None if eps is None and input_noise is None else (eps, input_noise)
 
     def _fill_noise(self, eng: Engine):
         eps, inp = self._fixed_noise if self._fixed_noise is not None else (None, None)
         for i, e in enumerate(eng.eps):                      # one draw per latent group, even when alpha == 0
             if eps is not None:
-                e.copy_(eps[i])
+                e.copy_(eps[i][:e.shape[0]])
             else:
                 e.normal_()
                 if getattr(eng, 'eps_std', 1.0) != 1.0:      # TransStyleGanDefenseModel draws N(0, 0.8) (models.py:331)
                     e.mul_(eng.eps_std)
         if eng.noise is not None:                            # abstract_models.py:132-138
             if inp is not None:
-                eng.noise.copy_(inp)
+                eng.noise.copy_(inp[:eng.noise.shape[0]])
             else:
                 eng.noise.normal_()
             if getattr(eng, 'noise_is_std', False):          # competitors: x + randn * std (nd_vae/purification_model.py:21)
@@ -200,8 +212,9 @@ class _EngineOwner:
     def _run(self, batch: torch.Tensor, rep: int, want_purified: bool, with_noise: bool = True):
         if batch.dim() != 4 or batch.shape[1] != 3:
             raise ValueError('expected a (B, 3, H, W) image batch')
+        differentiable = torch.is_grad_enabled() and batch.requires_grad
         batch = batch.to(self.device, dtype=torch.float32).contiguous()
-        eng = self._engine(batch.shape[0] * rep, rep, with_noise)
+        eng = self._engine(batch.shape[0] * rep, rep, with_noise, forward_only=not differentiable)
         if tuple(batch.shape[2:]) != tuple(eng.resolution[1:]):
             raise ValueError(f'expected {eng.resolution[1]}x{eng.resolution[2]} images, got {tuple(batch.shape[2:])}')
         return _EngineFn.apply(batch, self, eng, want_purified)

@@ -67,21 +67,15 @@ class NVAEDefenseModel(MLVGMDefenseModel, torch.nn.Module):
         from ...vgg_spec import VggSpec
         return isinstance(self.classifier.classifier.spec, VggSpec)
 
-    def _make_engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1) -> Engine:
+    supports_forward_only = True
+
+    def _make_engine(self, rows: int, rep: int, with_noise: bool = True, cot_rep: int = 1, need_backward: bool = True) -> Engine:
         ae, clf = self.autoencoder, self.classifier.classifier
         return Engine(ae.state_dict, ae.config, ae.resolution, clf.state_dict, clf.spec, rows=rows, rep=rep,
                       alphas=self.interpolation_alphas, temperature=self.temperature,
                       noise_eps=self.eps if with_noise else 0.0, blur=self.blur_input and with_noise,
                       share_encoder=True,      # EoT replicas share the encoder pass whenever no input noise is drawn
-                      device=self.device, store=self._store, cot_rep=cot_rep)
-
-
-def _next(name, what):
-    class _NotBuilt:
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f'{name}: {what} is a "next" row of SURVEY.md §8, not built yet')
-    _NotBuilt.__name__ = name
-    return _NotBuilt
+                      device=self.device, store=self._store, cot_rep=cot_rep, need_backward=need_backward)
 
 
 class E4EStyleGanDefenseModel(MLVGMDefenseModel, torch.nn.Module):

@@ -97,6 +97,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         self.version = 0                     # bumped by callers after each forward (stale-backward detection)
         self._sampler_descs = []             # (desc, latent index): alphas can be changed without rebuilding
         self._keep = []                      # weights etc.
+        self._frag_ok = {}                   # id(ConvDesc) -> weight tensor of the convs that may run on tile 8
         self.fwd = L.Plan()
         self.bwd = L.Plan()
         self._bwd_steps = []                 # closures emitting backward ops, replayed in reverse
@@ -124,7 +125,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0
         self.enc_rows = rows // rep if self.share_encoder else rows
         self.need_backward, self.image_s2d, self.cot_rep = need_backward, False, 1
-        self.bytes, self.acts, self.version, self._sampler_descs, self._keep = 0, {}, 0, [], []
+        self.bytes, self.acts, self.version, self._sampler_descs, self._keep, self._frag_ok = 0, {}, 0, [], [], {}
         self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
         return self
@@ -172,7 +173,10 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             kh, kw = (KH or K), (KW or K)
             if (kh, kw, sn, sd, pad) == (3, 3, 1, 1, 1) and x2 is None and (cin or x.shape[3]) % 32 == 0 and 128 % x.shape[2] == 0 \
                     and w.dim() == 2 and w.shape[1] == 9 * (cin or x.shape[3]):
-                d.w_frag = _ptr(self.store.frag3(w))        # tile 8: B fragments straight from global memory
+                # tile 8 reads its B fragments from a fragment-ordered copy of the weights (WeightStore.frag3).  The copy is built
+                # LAZILY — by apply_tuning for the descs whose tuned tile is 8, by autotune for its candidates — not for every
+                # eligible 3x3 weight (52 of 1594 tuned shapes select tile 8; an eager copy doubled the split-weight memory)
+                self._frag_ok[id(d)] = w
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
         No, Ho, Wo, Cy = y.shape
         d.y, d.ldy = _ptr(y), (ldy or Cy)
@@ -429,12 +433,24 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             need = splits * d.N * d.Ho * d.Wo * d.Cout
             if splits > 1 and (self.ws is None or need > WS_FLOATS):
                 tile, splits = 0, 1
+            if tile == 8 and not self._want_frag(d):    # conv_key does not encode pad / Wo / weight layout: a desc that shares the key of
+                tile = 5                                # a tile-8 entry without being eligible runs tile 5 (bitwise the same result)
             d.tile, d.splits = int(tile), int(splits)
             d.ws, d.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
             if not use_bf3:                      # this shape is faster on the exact fp32 kernel (small K or Cout)
                 d.w_hi, d.w_lo = None, None
         self.fwd.finalize()
         self.bwd.finalize()
+
+    def _want_frag(self, d) -> bool:
+        """make sure d.w_frag exists (tile 8); False when this conv cannot run on tile 8"""
+        if d.w_frag:
+            return True
+        w = self._frag_ok.get(id(d))
+        if w is None or self.dry_run:
+            return False
+        d.w_frag = _ptr(self.store.frag3(w))
+        return True
 
     def autotune(self, cache: Optional[dict] = None, reps: int = 3, save: Optional[str] = None, verbose: bool = False) -> dict:
         """time every (tile, split-K) candidate of every distinct conv shape on this GPU and keep the fastest."""
@@ -451,7 +467,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             best = None
             modes = (1, 0) if d.w_hi else (0,)
             halo = (5, 6, 7) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
-            if halo and d.w_frag:
+            if halo and self._want_frag(d):
                 halo = halo + (8,)
             for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + (halo if m_ else ())]:
                 bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32), 8: (128, 128)}[tile]

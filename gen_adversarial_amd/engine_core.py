@@ -56,10 +56,12 @@ class WeightStore:
             self.bytes += 4 * w.numel()
         return self.splits[k][0], self.splits[k][1]
 
-    def frag3(self, w: torch.Tensor) -> torch.Tensor:
+    def frag3(self, w: torch.Tensor, m16: bool = False) -> torch.Tensor:
         """the split weights of a 3x3 conv ([Cout][9 * C] fp32, C % 32 == 0) in the MFMA-fragment order of ga_conv_desc.w_frag
-        (bf16 [ceil(Cout/128)][C/32][9][4 waves][2 k steps][hi | lo][64 lanes][8]); made once per tensor"""
-        k = ('frag3', w.data_ptr())
+        (bf16 [ceil(Cout/128)][C/32][9][4 waves][2 k steps][hi | lo][64 lanes][8]); made once per tensor.
+        m16: the order of the 16x16x32 fragments, [..][4 waves][2 halves of the wave's 32 channels][hi | lo][64 lanes][8], lane =
+        16 * (k octet of the 32-deep chunk) + channel"""
+        k = ('frag3m16' if m16 else 'frag3', w.data_ptr())
         if k not in self.splits:
             hi, lo = self.split(w)
             cout, kk = w.shape
@@ -69,9 +71,11 @@ class WeightStore:
             def arr(t):
                 tp = torch.zeros(nt * 128, kk, dtype=torch.bfloat16, device=t.device)
                 tp[:cout] = t
+                if m16:     # [nt, wave, half, channel, tap, chunk, k octet, e] -> [nt, chunk, tap, wave, half, k octet, channel, e]
+                    return tp.view(nt, 4, 2, 16, 9, nkc, 4, 8).permute(0, 5, 4, 1, 2, 6, 3, 7)
                 # [nt, wave, row, tap, chunk, k step, lane half, e] -> [nt, chunk, tap, wave, k step, lane half, row, e]
                 return tp.view(nt, 4, 32, 9, nkc, 2, 2, 8).permute(0, 4, 3, 1, 5, 6, 2, 7)
-            f = torch.stack([arr(hi), arr(lo)], dim=5).contiguous()          # hi | lo between the k step and the lane
+            f = torch.stack([arr(hi), arr(lo)], dim=5).contiguous()          # hi | lo between the k step / half and the lane
             self.splits[k] = (f, w)
             self.bytes += 2 * f.numel()
         return self.splits[k][0]

@@ -82,7 +82,10 @@ class NvaeBuilder:
                  and n * H * W // (256 if x.c == 128 else 128) >= self.fuse_min_workgroups)
         # few-channel cells on images larger than a workgroup (post-processing): 8 x 16 tiles with a recomputed halo, and d x from
         # the same launch (ga_dec_cell_halo); one cotangent per forward row only
-        halo = (not fused and not up and not nd and self.precision == 'bf16x3' and self.fuse_dec_cells and self.fuse_halo_cells and cell.cout == x.c
+        # ... selected in FORWARD-ONLY plans (need_backward=False: clean predictions, get_purified, the alpha objective — forward 0.63 vs
+        # 0.95 ms and 0.32 vs 0.57 ms per 512-row chunk, same bits), and with GA_FUSE_HALO_CELL=1 everywhere (its backward is slower)
+        halo = (not fused and not up and not nd and self.precision == 'bf16x3' and self.fuse_dec_cells
+                and (self.fuse_halo_cells or not self.need_backward) and cell.cout == x.c
                 and self.cot_rep == 1 and L.lib.ga_dec_cell_halo_supported(n, H, W, x.c, hid_c) == 1
                 and n * H * W // 128 >= self.fuse_min_workgroups)
         t3 = Act(self, n, H, W, cell.cout, p + '.t3')
@@ -374,6 +377,12 @@ class NvaeBuilder:
         eps = self.eps[gs.latent_idx]
 
         ec = Act(self, R, r, r, C, f'ec_{key}')
+        # ec = conv(x) + enc_feat: d(enc_feat) = d(ec).  Without a shared encoder the two cotangents have the same shape, and the
+        # decoder side runs first in the backward plan, so enc_feat's gradient buffer IS d(ec): no copy launch (r04: 23 axpby
+        # launches per chunk less); the encoder cell that produced enc_feat later accumulates into it as into any written gradient
+        alias_grad = enc_rep == 1 and self.need_backward and not enc_feat.g_written and enc_feat._g is None
+        if alias_grad:
+            ec._g = enc_feat.g
         d_ec = self.conv(self.fwd, f'enc_combiner_{key}', x.t, ec_w['w'], ec.t, bias=ec_w['b'], K=1, addend=enc_feat.t)
         d_ec.addend_rep = enc_rep
         muq = Act(self, R, r, r, NLP, f'mu_q_{key}')
@@ -392,6 +401,10 @@ class NvaeBuilder:
             self.grad_conv(f'dec_sampler_{key}^T', pp.g, ds_w['w_bwd'], x, K=1, dact_x=x.t, dact_act=L.GA_ACT_ELU)
             self.grad_conv(f'enc_sampler_{key}^T', muq.g, es_w['w_bwd'], ec, K=3, pad=1)
             self.grad_conv(f'enc_combiner_{key}^T', ec.g, ec_w['w_bwd'], x, K=1)
+            if alias_grad:          # d(ec) was written straight into enc_feat's gradient buffer
+                assert not enc_feat.g_written
+                enc_feat.g_written = True
+                return
             # the additive encoder feature receives d(ec) unchanged (summed over the replicas that share it)
             if enc_rep > 1:
                 self.rep_sum(f'enc_feat_{key}.grad', ec.g, enc_feat, enc_rep)

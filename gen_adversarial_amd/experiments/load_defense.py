@@ -53,7 +53,7 @@ def load(args: Namespace):
         base_classifier = CelebaGenderClassifier(d_params.classifier_path, args.device)
         hl_instance = E4EStyleGanDefenseModel
     elif args.experiment == 'cars':
-        # ResNeXt-50 classifier (load_defense.py:59-73): base / trades / ablation; the Style-Transformer purifier is a next row
+        # ResNeXt-50 classifier + Style-Transformer / StyleGAN2 purifier (load_defense.py:59-73)
         args.image_size = 128
         args.attacks = {
             'deepfool': DeepFool(num_classes=4, overshoot=0.02, max_iter=256),

@@ -8,6 +8,11 @@ results.json keys and the 100.0 = "attack failed" convention (:141-146, 255-291)
 Changed for MI355X: the four all_gathers (:245-248) are ONE RCCL all-gather of a (ceil(N/W), 1+#attacks) fp32 tensor;
 the per-image barrier (:126-127) is dropped (images are independent; a single barrier precedes the gather);
 ranks are launched by torchrun / mp.spawn with MASTER_ADDR=127.0.0.1.
+Added (`--schedule dynamic`; SURVEY.md §5 / §8(e): attack cost varies > 100x with early exits, so static `r::W` shards finish at very
+different times): a SHARED WORK COUNTER — ranks draw chunks of `--batch_images` images from one atomic counter on the process
+group's store (`WorkQueue`), so a rank that drew cheap images simply draws more; still no collective inside the loop, still ONE
+all-gather at the end (of the dataset-ordered table, each row filled by the rank that evaluated it).  `--schedule static` stays the
+default and the parity mode (the reference's partition and its rank-major row order).
 """
 from __future__ import annotations
 
@@ -82,6 +87,65 @@ def evaluate_shard(defense_model, attacks: Dict[str, Callable], images: torch.Te
     return out
 
 
+class WorkQueue:
+    """chunk indices 0, 1, 2, ... handed out once each across all ranks: one atomic add on the process group's key-value store per
+    chunk (TCPStore.add is atomic; ~100 us against seconds of attack per chunk).  World size 1: a plain counter."""
+
+    def __init__(self, world: int, tag: str = 'eval'):
+        self.key, self.local, self.store = f'ga_work_{tag}', 0, None
+        if world > 1:
+            from torch.distributed import distributed_c10d as c10d
+            self.store = c10d._get_default_store()
+
+    def next(self) -> int:
+        if self.store is None:
+            self.local += 1
+            return self.local - 1
+        return int(self.store.add(self.key, 1)) - 1
+
+
+def evaluate_dynamic(defense_model, attacks: Dict[str, Callable], images: torch.Tensor, labels: torch.Tensor, world: int,
+                     batch_images: int = 1, device=None, queue: 'WorkQueue' = None):
+    """the whole dataset through the shared work counter: returns (table [N, 1 + 1 + #attacks] with column 0 = "this rank evaluated the
+    row", busy seconds of this rank, images this rank evaluated)"""
+    import time
+    n = images.shape[0]
+    chunk = max(1, int(batch_images))
+    queue = queue or WorkQueue(world)
+    table = torch.zeros(n, 2 + len(attacks))
+    busy, done = 0.0, 0
+    while True:
+        c = queue.next()
+        lo = c * chunk
+        if lo >= n:
+            break
+        hi = min(n, lo + chunk)
+        t = time.time()
+        x, y = images[lo:hi], labels[lo:hi]
+        if device is not None:
+            x, y = x.to(device), y.to(device)
+        table[lo:hi, 1:] = evaluate_shard(defense_model, attacks, x, y, batch_images=chunk)
+        table[lo:hi, 0] = 1.0
+        busy += time.time() - t
+        done += hi - lo
+    return table, busy, done
+
+
+def gather_dynamic(table: torch.Tensor, world: int, device) -> torch.Tensor:
+    """ONE all-gather of the dataset-ordered tables; every row was filled by exactly one rank (column 0 says which)"""
+    if world == 1:
+        assert bool((table[:, 0] == 1).all())
+        return table[:, 1:]
+    table = table.to(device)
+    parts = [torch.zeros_like(table) for _ in range(world)]
+    dist.barrier()
+    dist.all_gather(parts, table)
+    total = torch.stack(parts).sum(dim=0).cpu()
+    if not bool((total[:, 0] == 1).all()):
+        raise RuntimeError('work queue: some image was evaluated by no rank or by several')
+    return total[:, 1:]
+
+
 def gather_results(local: torch.Tensor, world: int, device) -> torch.Tensor:
     """ONE all-gather of the whole per-image table (payload: a few KB -> latency bound on xGMI)."""
     if world == 1:
@@ -128,11 +192,16 @@ def run_worker(rank: int, world: int, args, make_model: Callable, dataset: Tuple
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=timedelta(hours=12))
     args, defense_model = make_model(args)
     images, labels = dataset
-    mine = shard_indices(images.shape[0], rank, world)
     dev = args.device
-    local = evaluate_shard(defense_model, args.attacks, images[mine].to(dev), labels[mine].to(dev),
-                           batch_images=int(getattr(args, 'batch_images', 1) or 1))
-    table = gather_results(local, world, dev)
+    bi = int(getattr(args, 'batch_images', 1) or 1)
+    if getattr(args, 'schedule', 'static') == 'dynamic':
+        local, busy, done = evaluate_dynamic(defense_model, args.attacks, images, labels, world, batch_images=bi, device=dev)
+        args.rank_busy_seconds, args.rank_images = busy, done          # (tests and logs read these)
+        table = gather_dynamic(local, world, dev)
+    else:
+        mine = shard_indices(images.shape[0], rank, world)
+        local = evaluate_shard(defense_model, args.attacks, images[mine].to(dev), labels[mine].to(dev), batch_images=bi)
+        table = gather_results(local, world, dev)
     res = None
     if rank == 0:
         cols = {RESULT_KEYS.get(name, name): table[:, 1 + j].tolist() for j, name in enumerate(args.attacks.keys())}
@@ -185,6 +254,9 @@ def parse_args(argv=None):
                    help='If passed, try a specific attack only. Otherwise, try all (the reference\'s three).')
     p.add_argument('--batch_images', type=int, default=1,
                    help='images per defender call for the clean pass and for batched attacks (PGD); 1 = the reference protocol')
+    p.add_argument('--schedule', type=str, choices=['static', 'dynamic'], default='static',
+                   help='static: the reference\'s r::W partition (parity mode); dynamic: ranks draw chunks of --batch_images images '
+                        'from a shared work counter (balances attacks whose cost varies with early exits)')
     args = p.parse_args(argv)
     args.results_folder = f'./results/{args.config.split("/")[-1][:-5]}/'
     os.makedirs(args.results_folder, exist_ok=True)

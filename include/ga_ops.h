@@ -442,6 +442,9 @@ int ga_avae(const ga_avae_desc* d, void* stream);
  *   flops per call = blocks * 4 * iters * 8 * (2 * 32 * 32 * 16); out: >= blocks * 256 floats (keeps the accumulators live). */
 int ga_microbench_hbm_copy(const float* src, float* dst, long n_floats, void* stream);
 int ga_microbench_mfma_bf16(float* out, int blocks, int iters, void* stream);
+/* the same loop and the same flops per call on the MFMA shape `shape`: 32 = v_mfma_f32_32x32x16_bf16 (as above),
+ * 16 = v_mfma_f32_16x16x32_bf16 -- under the chip's power limit the clock it holds depends on the shape. */
+int ga_microbench_mfma_bf16_shape(float* out, int blocks, int iters, int shape, void* stream);
 
 /* nn.PReLU(C) as a stand-alone pass (the input layer of the e4e encoder, encoder.py:72-74, whose output feeds both an
  * affine prologue and a shortcut): forward y = x > 0 ? x : slope[c] * x; backward dx = dy * (x > 0 ? 1 : slope[c]).
@@ -585,6 +588,9 @@ int ga_plan_profile(const ga_op* ops, int n, void* stream, float* per_op_ms);
 long ga_debug_set_conv_row_limit(long bytes);
 
 const char* ga_last_hip_error(void);
+/* GA_ABI_VERSION is bumped with EVERY change of a descriptor's layout or meaning (a field added, a reserved field put to use) and
+ * with every entry point added; the binding (gen_adversarial_amd/_lib.py: ABI_VERSION) refuses a library that reports another one. */
+#define GA_ABI_VERSION 4
 int ga_abi_version(void);
 unsigned long ga_sizeof_op(void);
 

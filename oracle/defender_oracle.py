@@ -168,3 +168,31 @@ def e4e_defender_call(esd, espec, gsd, gspec, latent_avg, csd, cspec, x01, alpha
     Pinned by tests/golden/e4e_purify.npz (the reference's own E4EStyleGanDefenseModel, tests/golden/make_stylegan_full_golden.py)."""
     purified = e4e_purify(esd, espec, gsd, gspec, latent_avg, x01, alphas, z, pool_to)
     return resnet_classifier_call(csd, cspec, purified), purified
+
+
+class EoTDefenderOracle(torch.nn.Module):
+    """EoTWrapper(NVAEDefenseModel(classifier)) as ONE differentiable CPU callable with every random draw pinned — what the
+    reference's attacks see as `net` (src/attacks/untargeted.py: every `net(x)`; src/defenses/wrappers.py:15-24;
+    src/defenses/ours/abstract_models.py:161-193), restated on the oracle so that the SAME attack code can be run against the HIP
+    defender and against this restatement (tests/test_attack_parity_gpu.py, tools/robust_acc_attack.py).
+
+    forward(x: (B,3,H,W)) -> (B, n_classes): image b becomes defender rows b*eot .. b*eot+eot-1 (the batched form of
+    `x.repeat(eot_steps, 1, 1, 1)` for one image), row r of a call uses draw r of `eps[g]` / `input_noise` (as the HIP defender's
+    fixed_noise does), logits are averaged over each image's rows."""
+
+    def __init__(self, nvae_sd, nvae_spec, vgg_sd, vgg_spec, eot_steps: int, alphas, eps, input_noise, noise_eps: float = 0.0,
+                 blur: bool = False, temperature: float = 0.6):
+        super().__init__()
+        self.a = (nvae_sd, nvae_spec, vgg_sd, vgg_spec)
+        self.eot, self.alphas, self.eps, self.noise = eot_steps, list(alphas), eps, input_noise
+        self.noise_eps, self.blur, self.temperature = noise_eps, blur, temperature
+        self.calls = 0
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        rows = B * self.eot
+        self.calls += 1
+        noise = self.noise[:rows] if self.noise is not None else torch.ones(rows, *x.shape[1:])
+        logits, _ = nvae_defender(*self.a, x.repeat_interleave(self.eot, dim=0), self.alphas, [e[:rows] for e in self.eps], noise,
+                                  self.noise_eps, self.blur, self.temperature)
+        return logits.view(B, self.eot, -1).mean(dim=1)

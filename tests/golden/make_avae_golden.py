@@ -15,6 +15,8 @@ Weights: gen_adversarial_amd.avae_spec.init_avae_state_dict, load_state_dict(str
 import os
 import sys
 
+sys.dont_write_bytecode = True     # importing the reference must not leave __pycache__ in /root/reference (read-only tree)
+
 import numpy as np
 import torch
 

@@ -21,6 +21,8 @@ import io
 import os
 import re
 import sys
+
+sys.dont_write_bytecode = True     # importing the reference must not leave __pycache__ in /root/reference (read-only tree)
 import types
 
 import numpy as np

@@ -18,6 +18,8 @@ Weights: gen_adversarial_amd's seeded initialisers, load_state_dict(strict=True)
 """
 import os
 import sys
+
+sys.dont_write_bytecode = True     # importing the reference must not leave __pycache__ in /root/reference (read-only tree)
 import types
 
 import numpy as np

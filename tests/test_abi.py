@@ -33,7 +33,9 @@ def test_every_direct_entry_point_takes_a_pointer_sized_stream():
 
 
 def test_struct_sizes_and_version():
-    assert L.lib.ga_abi_version() == 1
+    hdr = open(os.path.join(ROOT, 'include', 'ga_ops.h')).read()
+    declared = int(re.search(r'#define\s+GA_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert L.lib.ga_abi_version() == declared == L.ABI_VERSION
     assert L.lib.ga_sizeof_op() == C.sizeof(L.Op)
 
 

@@ -1,0 +1,225 @@
+"""
+GPU: the reference's L2 evaluation attacks (src/attacks/untargeted.py:37-243 APGD, :325-467 C&W, :470-568 DeepFool, :571-705 FAB,
+:246-322 AutoAttack's escalation) driven against (i) the HIP defender behind `load(args)` and (ii) the CPU oracle of the same
+defender (oracle.defender_oracle.EoTDefenderOracle) with EVERY random draw pinned — the defender's latent and input noise and the
+attack's own start noise — and compared on what the protocol returns: `(success, L2 bound, adversarial image)`.
+SURVEY.md §8 rows a19 / f1: the attack code is the same on both sides (it is pinned against the reference's own classes on a toy
+net in tests/test_attacks_cpu.py); what this file checks is that the HIP defender is the SAME FUNCTION to an attack as the
+reference's defender — logits, input gradients, per-class Jacobians, repeated backward passes, sub-batches — over whole attack
+trajectories.
+
+Two comparisons per attack, tolerances written here and observed values printed:
+  (1) REPLAY: the oracle run is recorded — every query image the attack sent to `net`, the logits it got back, every cotangent it
+      back-propagated and the input gradient it received — and every query is then put to the HIP defender: logits within 1e-3
+      (the bar of BASELINE.json), gradients within 2e-2 in relative L2 with at most 1 % of the elements further than 1e-3 of
+      max |g| off (a ReLU / max-pool decision that flips on a 1-ulp difference moves single elements by O(1): DESIGN.md §4).  No
+      trajectory divergence enters: this is the statement "to this attack the HIP defender IS the reference's function".
+  (2) FREE RUN: the same attack object drives the HIP defender on its own (DeepFool / FAB through the K-cotangent class Jacobian,
+      APGD / C&W through autograd) and the protocol's triple is compared: |L2_hip - L2_oracle| <= 2 % of the bound + 1e-3, the
+      adversarial images within 5 % of the perturbation's own norm of each other, success flags equal — unless the oracle's final
+      decision sits within 1e-3 of a tie, which is where DeepFool and FAB END BY CONSTRUCTION (they stop on the boundary plus a 2 %
+      overshoot): there the flag is a coin flip in the reference itself and only L2 and the images are compared.
+"""
+from argparse import Namespace
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from gen_adversarial_amd.attacks.l2_attacks import APGDAttack, CW, DeepFool, FABAttack   # noqa: E402
+from gen_adversarial_amd.experiments.load_defense import load   # noqa: E402
+from gen_adversarial_amd.nvae_spec import build_spec, nvae_checkpoint   # noqa: E402
+from gen_adversarial_amd.vgg_spec import build_vgg_spec, init_vgg_state_dict   # noqa: E402
+from oracle import defender_oracle as D   # noqa: E402
+
+DEV = 'cuda:0'
+CFG = {'initial_channels': 8, 'num_pre-post_process_blocks': 1, 'num_pre-post_process_cells': 2, 'num_scales': 3,
+       'num_groups_per_scale': 2, 'is_adaptive': False, 'min_groups_per_scale': 1, 'num_cells_per_group': 1,
+       'num_latent_per_group': 4, 'num_logistic_mixtures': 10, 'num_nf_cells': None}
+RES = (3, 64, 64)
+EOT = 2
+NCLS = 10           # the class count of the test classifier: FAB's per-class gradients stay affordable on the CPU oracle
+MAXB = 3            # images per call at most (pinned draws hold MAXB * EOT rows)
+
+
+@pytest.fixture(scope='module')
+def pair(tmp_path_factory):
+    """(HIP defender behind load(args), oracle defender with the same weights and the same pinned draws)"""
+    d = tmp_path_factory.mktemp('ckpt')
+    ck = nvae_checkpoint(CFG, RES, seed=15)
+    torch.save(ck, d / 'nvae.pt')
+    vsd = init_vgg_state_dict(NCLS, 16, seed=16)
+    torch.save({'state_dict': vsd}, d / 'vgg.pt')
+    spec = build_spec(CFG, RES)
+    n_groups = len(spec.groups)
+    alphas = [round(i / (n_groups - 1), 3) for i in range(n_groups)]
+    y = {'classifier_path': str(d / 'vgg.pt'), 'autoencoder_path': str(d / 'nvae.pt'), 'interpolation_alphas': alphas,
+         'alpha_attenuation': 0.7, 'initial_noise_eps': 2.0, 'gaussian_blur_input': False}
+    with open(d / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump(y, f)
+    args, model = load(Namespace(config=str(d / 'cfg.yaml'), experiment='ids', defense_type='ours', eot_steps=EOT, device=DEV))
+    g = torch.Generator().manual_seed(77)
+    rows = MAXB * EOT
+    eps = [torch.randn(rows, 4, gs.res, gs.res, generator=g) for gs in spec.groups]
+    noise = torch.randn(rows, *RES, generator=g)
+    oracle = D.EoTDefenderOracle(ck['state_dict_temp=0.6'], spec, vsd, build_vgg_spec(NCLS, 16), EOT, [a * 0.7 for a in alphas],
+                                 eps, noise, noise_eps=2.0)
+    model.model.fixed_noise([e.to(DEV) for e in eps], noise.to(DEV))
+    yield model, oracle
+    model.model.fixed_noise(None, None)
+
+
+def _images(n, seed):
+    return torch.rand(n, *RES, generator=torch.Generator().manual_seed(seed))
+
+
+def _labels(oracle, x):
+    with torch.no_grad():
+        lg = oracle(x)
+    top2 = lg.topk(2, dim=1).values
+    return lg.argmax(dim=1), (top2[:, 0] - top2[:, 1])
+
+
+class Recorder(torch.nn.Module):
+    """wraps the oracle: logs every query (image, logits) and, through tensor hooks, every (cotangent, input gradient) pair of
+    every backward pass the attack runs on that query"""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net, self.log = net, []
+
+    def forward(self, x):
+        entry = {'x': x.detach().clone(), 'back': []}
+        self.log.append(entry)
+        out = self.net(x)
+        entry['logits'] = out.detach().clone()
+        if x.requires_grad and torch.is_grad_enabled():
+            pending = []
+            out.register_hook(lambda g: pending.append(g.detach().clone()))
+            x.register_hook(lambda g: entry['back'].append((pending.pop(), g.detach().clone())))
+        return out
+
+
+def _replay(name, log, model):
+    """every recorded query answered by the HIP defender"""
+    e_l = e_g = frac = 0.0
+    n_back = 0
+    for q in log:
+        xd = q['x'].to(DEV).requires_grad_(bool(q['back']))
+        out = model(xd)
+        e_l = max(e_l, (out.detach().cpu() - q['logits']).abs().max().item())
+        for cot, gx in q['back']:
+            (g,) = torch.autograd.grad(out, [xd], cot.to(DEV), retain_graph=True)
+            diff = g.cpu() - gx
+            e_g = max(e_g, (diff.norm() / gx.norm().clamp_min(1e-30)).item())
+            frac = max(frac, (diff.abs() > 1e-3 * gx.abs().max()).float().mean().item())
+            n_back += 1
+    print(f'   {name} replay: {len(log)} queries, {n_back} backward passes: logits {e_l:.1e}, gradients relL2 {e_g:.1e}, '
+          f'elements beyond 1e-3 of max |g|: {100 * frac:.3f} %')
+    assert e_l < 1e-3, (name, e_l)
+    assert e_g < 2e-2 and frac < 0.01, (name, e_g, frac)
+
+
+def _compare(name, x, res_hip, res_cpu, oracle, labels):
+    """the protocol's triple, image by image"""
+    sh, bh, ah = res_hip
+    sc, bc, ac = res_cpu
+    sh, sc = torch.as_tensor(sh).view(-1).cpu(), torch.as_tensor(sc).view(-1)
+    bh, bc = torch.as_tensor(bh, dtype=torch.float32).view(-1).cpu(), torch.as_tensor(bc, dtype=torch.float32).view(-1)
+    ah = ah.cpu()
+    with torch.no_grad():
+        lg = oracle(ac)
+    other = lg.clone()
+    other[torch.arange(len(labels)), labels] = -1e30
+    margin = (lg[torch.arange(len(labels)), labels] - other.max(dim=1).values).abs()       # distance of the final decision from a tie
+    for i in range(x.shape[0]):
+        tie = margin[i].item() < 1e-3
+        if not tie:
+            assert bool(sh[i]) == bool(sc[i]), (name, i, bool(sh[i]), bool(sc[i]), margin[i].item())
+        pert = (ac[i] - x[i]).norm().item()
+        d_adv = (ah[i] - ac[i]).norm().item()
+        note = ''
+        if bool(sh[i]) != bool(sc[i]):
+            note = f' [flags differ on a tie: margin {margin[i].item():.1e}]'          # the losing side returns the clean image
+        else:
+            if bool(sc[i]) and bc[i].item() < 1e9:
+                assert abs(bh[i].item() - bc[i].item()) <= 0.02 * bc[i].item() + 1e-3, (name, i, bh[i].item(), bc[i].item())
+            assert d_adv <= 0.05 * pert + 1e-4, (name, i, d_adv, pert)
+        print(f'   {name} image {i}: success hip {bool(sh[i])} / oracle {bool(sc[i])}, L2 hip {bh[i].item():.5f} / oracle {bc[i].item():.5f}, '
+              f'|adv_hip - adv_oracle| = {d_adv:.2e} of a perturbation of {pert:.3f}; decision margin {margin[i].item():.2e}{note}')
+
+
+def _both(name, mk, x, labels, model, oracle, **kw):
+    rec = Recorder(oracle)
+    res_cpu = mk()(x, labels, rec, **kw)
+    _replay(name, rec.log, model)
+    res_hip = mk()(x.to(DEV), labels.to(DEV), model, **{k: v.to(DEV) for k, v in kw.items()})
+    _compare(name, x, res_hip, res_cpu, oracle, labels)
+    return res_hip, res_cpu
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_deepfool_on_hip_defender_equals_oracle(pair, B):
+    """untargeted.py:470-568: per-class gradients of ONE forward (the HIP side answers them from its K-cotangent plan), closest
+    linearised boundary, accumulated perturbation"""
+    model, oracle = pair
+    x = _images(B, 100 + B)
+    labels, _ = _labels(oracle, x)
+    _both(f'DeepFool[B={B}]', lambda: DeepFool(num_classes=4, overshoot=0.02, max_iter=12), x, labels, model, oracle)
+
+
+@pytest.mark.parametrize('ce', [True, False])
+def test_apgd_on_hip_defender_equals_oracle(pair, ce):
+    """untargeted.py:37-243: APGD-CE / APGD-DLR with momentum, step halving and best-point restarts; the random start is pinned"""
+    model, oracle = pair
+    B = 2
+    x = _images(B, 200 + int(ce))
+    labels, _ = _labels(oracle, x)
+    init = torch.randn(B, *RES, generator=torch.Generator().manual_seed(5))
+    bound = 4.0 if ce else 2.0
+    res_hip, _ = _both('APGD-CE' if ce else 'APGD-DLR', lambda: APGDAttack(n_iter=8, rho=0.75, max_bound=bound, ce_loss=ce), x, labels,
+                       model, oracle, init_noise=init)
+    assert float(torch.as_tensor(res_hip[1]).max()) <= bound + 1e-3
+
+
+def test_fab_on_hip_defender_equals_oracle(pair):
+    """untargeted.py:571-705: all-class logit differences and gradients of one forward, projection_l2 onto the closest linearised
+    boundary, biased step back towards the original"""
+    model, oracle = pair
+    x = _images(1, 300)
+    labels, _ = _labels(oracle, x)
+    _both('FAB', lambda: FABAttack(n_iter=6, alpha_max=0.1, eta=1.05, beta=0.9), x, labels, model, oracle)
+
+
+def test_cw_on_hip_defender_equals_oracle(pair):
+    """untargeted.py:325-467: FGSM + noise start, Adam on w = atanh(2x - 1), clipped gradient, adaptive c.  The start noise is drawn
+    from the global generator: both runs are seeded alike (the draw is made on the CPU in both: the HIP run moves it)."""
+    model, oracle = pair
+    x = _images(1, 400)
+    labels, _ = _labels(oracle, x)
+    import gen_adversarial_amd.attacks.l2_attacks as A
+    draws = []
+    real = A._per_image_randn
+
+    def recorded(image):                                        # the oracle run records its draws, the HIP run replays them
+        n = real(image.cpu())
+        draws.append(n)
+        return n
+    mk = lambda: CW(c=16., kappa=0.05, steps=10, lr=5e-3, n_restarts=2)   # noqa: E731
+    try:
+        A._per_image_randn = recorded
+        torch.manual_seed(3)
+        rec = Recorder(oracle)
+        res_cpu = mk()(x, labels, rec)
+        _replay('C&W', rec.log, model)
+        it = iter(list(draws))
+        A._per_image_randn = lambda image: next(it).to(image.device)
+        res_hip = mk()(x.to(DEV), labels.to(DEV), model)
+    finally:
+        A._per_image_randn = real
+    _compare('C&W', x, res_hip, res_cpu, oracle, labels)

@@ -10,8 +10,8 @@ BASELINE.json configs[2] and configs[4] AT THEIR OWN SIZES AND SETTINGS against 
               ResNeXt-50 32x4d (4 classes), the yaml's 16 learned alphas x 0.7, two images x EoT 32 = the 64-row plan bench.py times.
 
 Random weights of the reference architectures (no checkpoint exists offline).  Rows are independent, so the oracle is run on
-rows 0..K-1 of the plan (image 0 under its first K noise / latent draws) and the cotangent is zero on the other rows:
-logits and purified image at 1e-3 (north_star), the input gradient on every element given the engine's ReLU / PReLU / LeakyReLU /
+rows 0..K-1 of the plan (K = 4: image 0 under its first four noise / latent draws) and the cotangent is zero on the other rows:
+logits and purified image at an ABSOLUTE 1e-3 (north_star), the input gradient on every element given the engine's ReLU / PReLU / LeakyReLU /
 max-pool decisions (tests/gradcheck.py).  Plus the size-independent properties: replicas with equal draws are bitwise equal rows,
 two forwards are bitwise equal, the backward pass is linear in its cotangent, images without a cotangent get no gradient.
 The oracle runs take ~15 s (configs[2], one row forward + backward at 1024 px) per evaluation on the box's 16 cores.
@@ -64,7 +64,7 @@ def _properties(eng, rows, rep, ncls, fill, gen):
 
 def test_configs2_e4e_defender_32_rows_yaml_alphas_noise_eps_4():
     from oracle import defender_oracle as D
-    rows, rep, k = 32, 32, 2
+    rows, rep, k = 32, 32, 4
     eng, y, (esd, espec, gsd, gspec, avg, csd, cspec, alphas) = build_e4e_defender(DEV, rows, rep, 'bf16x3', parts=True)
     assert float(y['initial_noise_eps']) == 4.0 and len(alphas) == 18 and not eng.share_encoder and eng.noise is not None
     assert (gspec.size, espec.n_styles if hasattr(espec, 'n_styles') else 18) == (1024, 18)
@@ -97,17 +97,19 @@ def test_configs2_e4e_defender_32_rows_yaml_alphas_noise_eps_4():
         lg, pur = call(x)
     e_l, e_p = err(logits[:k], lg), err(purified[:k], pur)
     print(f'configs[2] 32-row plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} (|logits| {lg.abs().max().item():.1f}) purified {e_p:.2e}')
-    assert e_l < TOL * max(1.0, lg.abs().max().item()) and e_p < TOL
+    # ABSOLUTE 1e-3 (north_star's bar as stated; a bound relative to max |logit| = 83 of this random-weight ResNet-50 would let a 50x
+    # regression pass: VERDICT r03 weak #3), on 4 rows
+    assert e_l < TOL and e_p < TOL
     eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
     eng.backward()
     from gradcheck import assert_grad_given_engine_decisions
     assert_grad_given_engine_decisions(eng, lambda t: (call(t)[0] * cot[:k]).sum(), x, eng.dx, 1e-3,
-                                       'configs[2] input gradient of rows 0..1 inside the 32-row plan', min_matched=20, rows=slice(0, k))
+                                       'configs[2] input gradient of rows 0..3 inside the 32-row plan', min_matched=20, rows=slice(0, k))
 
 
 def test_configs4_trans_defender_64_rows_yaml_alphas_blur():
     from oracle import defender_oracle as D, trans_oracle as T
-    rows, rep, k = 64, 32, 2
+    rows, rep, k = 64, 32, 4
     eng, y, (tsd, tspec, gsd, gspec, avg, csd, cspec, alphas) = build_trans_defender(DEV, rows, rep, 'bf16x3', parts=True)
     assert bool(y['gaussian_blur_input']) and eng.blur and len(alphas) == 16 and abs(alphas[0] - 0.7) < 1e-12 and gspec.size == 512
     assert D.blur_kernel_size(128) == 31
@@ -137,10 +139,10 @@ def test_configs4_trans_defender_64_rows_yaml_alphas_blur():
         lg, pur = call(x[:1])
     e_l, e_p = err(logits[:k], lg), err(purified[:k], pur)
     print(f'configs[4] 64-row plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} (|logits| {lg.abs().max().item():.1f}) purified {e_p:.2e}')
-    assert e_l < TOL * max(1.0, lg.abs().max().item()) and e_p < TOL
+    assert e_l < TOL and e_p < TOL                            # absolute, 4 rows
     eng.dlogits.view(rows, -1).copy_(cot.to(DEV))
     eng.backward()
     assert float(eng.dx[1:].abs().max()) == 0.0               # image 1's rows carry no cotangent
     from gradcheck import assert_grad_given_engine_decisions
     assert_grad_given_engine_decisions(eng, lambda t: (call(t)[0] * cot[:k]).sum(), x[:1], eng.dx[:1], 1e-3,
-                                       'configs[4] input gradient of rows 0..1 inside the 64-row plan', min_matched=20, rows=slice(0, k))
+                                       'configs[4] input gradient of rows 0..3 inside the 64-row plan', min_matched=20, rows=slice(0, k))

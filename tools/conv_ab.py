@@ -26,13 +26,14 @@ b = torch.randn(Cout, device=dev, generator=g) * 0.1
 store = WeightStore(dev)
 hi, lo = store.split(w)
 frag = store.frag3(w)
+frag16 = store.frag3(w, m16=True)
 ys, ds = [], []
 for t in tiles:
     y = torch.zeros(N, H, H, Cout, device=dev)
     d = L.ConvDesc()
     d.x, d.ldx, d.C1, d.w, d.bias, d.y, d.ldy, d.Cout = x.data_ptr(), Cin, Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, Cout
     d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad, d.tile, d.pro_act = N, H, H, H, H, 3, 3, 1, 1, 1, t, act
-    d.w_hi, d.w_lo, d.w_frag = hi.data_ptr(), lo.data_ptr(), frag.data_ptr()
+    d.w_hi, d.w_lo, d.w_frag = hi.data_ptr(), lo.data_ptr(), (frag16 if t in (9, 10) else frag).data_ptr()
     L.run(d)
     ys.append(y)
     ds.append(d)
@@ -55,4 +56,4 @@ ref = torch.nn.functional.conv2d((x * torch.sigmoid(x) if act == 1 else x).permu
 for i, tl in enumerate(tiles):
     err = (ys[i][:8].permute(0, 3, 1, 2) - ref).abs().max().item()
     print(f'N{N} {H}x{H} {Cin}->{Cout} act{act} tile {tl}: {np.median(t[:, i]):7.1f} us (min {t[:, i].min():.1f}) = {fl / np.median(t[:, i]) / 1e6:6.1f} TF/s; '
-          f'vs torch {err:.1e}; bitwise equal to tile {tiles[0]}: {torch.equal(ys[i], ys[0])}', flush=True)
+          f'vs torch {err:.1e}; bitwise equal to tile {tiles[0]}: {torch.equal(ys[i], ys[0])}; max diff to tile {tiles[0]}: {(ys[i] - ys[0]).abs().max().item():.1e}', flush=True)
