@@ -7,7 +7,7 @@ One "step" = one white-box attack iteration over one batch of images:
 with fresh N(0,1) latent noise every step, synthetic images already resident in HBM.
 Workload at N=1: BASELINE.json configs[1] — NVAE purify, CelebA-64 shapes, bs = 256 images (x EoT 32 = 8192 defender
 rows), fp32-class arithmetic, alphas of configs/ours_cosine_no_preprocessing_ids.yaml x 0.7, assumed NVAE config of
-SURVEY.md §6.  The 8192 rows of a step run as chunks of --chunk-rows rows (activations of a 512-row chunk: 67 GB),
+SURVEY.md §6.  The 8192 rows of a step run as chunks of --chunk-rows rows (default 1024: 90 GB of activations per chunk plan),
 alternating over --streams engines on their own HIP streams so that one chunk's kernel tails overlap the other's.
 N>1: the same batch per rank (weak scaling, images are independent), one RCCL all-gather of accuracy counters.
 """
@@ -404,10 +404,10 @@ def secondary_measurements(out, args, device, model, store, x, labels):
         log('secondary: reference protocol (1 image x EoT 32) ...')
         e1, _ = build_model(device, args.eot, args.eot, seed=0, precision=args.precision, share_encoder=False, store=store)
         st = AttackStep([e1], [torch.cuda.Stream(device=device)], labels[:1].clone(), x[:1].clone())
-        t_eager = _time_steps(st, 20, warm=3)
+        t_eager = _time_steps(st, 8, warm=2)
         with torch.cuda.stream(st.streams[0]):
             e1.enable_graphs()
-        t_graph = _time_steps(st, 20, warm=3)
+        t_graph = _time_steps(st, 8, warm=2)
         e1.disable_graphs()
         sec['reference_protocol_1_image'] = {'rows_per_s_eager': args.eot / t_eager, 'ms_per_step_eager': t_eager * 1e3,
                                              'rows_per_s_hip_graph': args.eot / t_graph, 'ms_per_step_hip_graph': t_graph * 1e3,
@@ -416,8 +416,22 @@ def secondary_measurements(out, args, device, model, store, x, labels):
                                                      'attacks use); literal x.repeat(eot) path'}
         del st, e1
         free_gpu_memory()
+        # the same call through the defender API's default: configs[1]'s yaml has initial_noise_eps 0.0, so the 32 EoT replicas of the
+        # image are identical up to the first latent draw and the encoder runs once per image (exact) — what a drop-in
+        # user of the reference's protocol gets
+        e1s, _ = build_model(device, args.eot, args.eot, seed=0, precision=args.precision, share_encoder=True, store=store)
+        sts = AttackStep([e1s], [torch.cuda.Stream(device=device)], labels[:1].clone(), x[:1].clone())
+        t_sh = _time_steps(sts, 8, warm=2)
+        sec['reference_protocol_1_image'].update({
+            'rows_per_s_api_default_shared_encoder': args.eot / t_sh, 'ms_per_step_api_default_shared_encoder': t_sh * 1e3,
+            'launches_per_step_api_default_shared_encoder': len(e1s.fwd) + len(e1s.bwd),
+            'api_default_note': 'NVAEDefenseModel runs the (deterministic) encoder once per image when no input noise is configured '
+                                '(configs[1]: initial_noise_eps 0.0); same logits and gradients as the literal repeat'})
+        del sts, e1s
+        free_gpu_memory()
     except Exception as ex:
-        sec['reference_protocol_1_image'] = {'rows_per_s_eager': None, 'what': f'failed: {ex}'}
+        sec.setdefault('reference_protocol_1_image', {})['failure'] = f'failed: {ex}'
+        sec['reference_protocol_1_image'].setdefault('rows_per_s_eager', None)
     # ---- per-class input gradients (DeepFool: 10 classes; FAB on the ids experiment: 100) — one forward + one backward per class
     #      (the reference: src/attacks/untargeted.py:526-560, :605-635) against the K-cotangent backward plan
     try:
@@ -469,7 +483,7 @@ def class_jacobian_measurement(args, device, store):
                 e.backward()
         entry = {'rows': rows, 'K': K, 'what': f'{images} image(s) x EoT {args.eot}: one forward + the input gradients of C class logits'}
         for C, name in ((10, 'deepfool_10_classes'), (100, 'fab_100_classes')):
-            n = 3 if C * rows > 2000 else 10
+            n = 2 if C * rows > 2000 else 5
             t1 = _time_steps(lambda: iteration(e1, C), n, warm=1)
             tK = _time_steps(lambda: iteration(eK, C), n, warm=1)
             entry[name] = {'ms_per_class_loop': t1 * 1e3, 'backward_replays_per_class_loop': C,
@@ -507,6 +521,18 @@ def defender_parity(eng, oracle_call, res_px, n_latent, noise_eps, eps_std=1.0):
                     'for logits); gradients: tests/test_fullsize_configs_gpu.py'}
 
 
+def _scale_head(csd, s):
+    """The random-weight classifiers behind the random-weight generators put out logits of |20| (ResNeXt-50) to |160| (ResNet-50).
+    The split-bf16 path carries a RELATIVE error of ~1.7e-5 of max |logit| through these networks (measured: 2.7e-3 at |163|, 1.7e-4
+    at |10|; the CPU oracle's own fp32-vs-fp64 difference on the classifier is 4e-6 at |10|, so this is the arithmetic, not the
+    comparison), which meets north_star's ABSOLUTE 1e-3 for |logits| up to ~60.  Trained classifiers put out |logits| of 10 - 20:
+    the head's last layer is scaled so that the random-weight stand-ins do too, and tests/test_fullsize_configs_gpu.py asserts the
+    absolute bar there (a bound relative to |83| would let a 50x regression pass).  No effect on the arithmetic
+    that is timed."""
+    csd['model.fc.3.weight'] = csd['model.fc.3.weight'] * s
+    csd['model.fc.3.bias'] = csd['model.fc.3.bias'] * s
+
+
 def build_trans_defender(device, rows, eot, precision, parts=False):
     """BASELINE.json configs[4] (configs/ours_learned_blur_cars.yaml: 16 learned alphas x 0.7, Gaussian blur of the input): the
     Style-Transformer encoder (IR-SE50 at 192 x 256 + 3 decoder layers over 16 queries) + StyleGAN2-512 + ResNeXt-50 32x4d at
@@ -522,6 +548,7 @@ def build_trans_defender(device, rows, eot, precision, parts=False):
     gspec = build_stylegan_spec(512)
     gsd = init_stylegan_state_dict(gspec, 1)
     cspec, csd = build_resnet_spec(4, 1, (3, 4, 6, 3), 32, 4), init_resnet_state_dict(4, 1, 2, (3, 4, 6, 3), 32, 4)
+    _scale_head(csd, 0.5)
     avg = 0.1 * torch.randn(16, 512, generator=torch.Generator().manual_seed(5))
     eng = Engine.bare(rows, device=device, precision=precision, rep=eot, resolution=(3, 128, 128), alphas=alphas,
                       noise_eps=float(y['initial_noise_eps']), blur=bool(y['gaussian_blur_input']), share_encoder=False)
@@ -598,6 +625,7 @@ def build_e4e_defender(device, rows, eot, precision, parts=False):
     gspec = build_stylegan_spec(1024)
     gsd = init_stylegan_state_dict(gspec, 1)
     cspec, csd = build_resnet_spec(2), init_resnet_state_dict(2, 1, 2)
+    _scale_head(csd, 1.0 / 16.0)
     avg = 0.1 * torch.randn(18, 512, generator=torch.Generator().manual_seed(5))
     eng = Engine.bare(rows, device=device, precision=precision, rep=eot, resolution=(3, 256, 256), alphas=alphas,
                       noise_eps=float(y['initial_noise_eps']))
@@ -733,8 +761,11 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--images', type=int, default=256, help='images per GPU per step (bs of BASELINE.json configs[1])')
     ap.add_argument('--eot', type=int, default=32)
-    ap.add_argument('--chunk-rows', type=int, default=512,
-                    help='defender rows (images x EoT) one plan run processes; a 512-row chunk holds 67 GB of activations')
+    ap.add_argument('--chunk-rows', type=int, default=1024,
+                    help='defender rows (images x EoT) one plan run processes: a 1024-row chunk holds 90 GB of activations, two of them '
+                         '(--streams 2) 180 of the 288 GB.  512-row chunks (95 GB in all) run 1.5 - 1.9 %% slower (interleaved runs on '
+                         'one box, gpurun_out/r04_chunk_ab.log): the 3x3 layers at 8x8 and 4x4 then launch ONE wave of workgroups, '
+                         'whose setup and epilogue phases coincide on every CU')
     ap.add_argument('--streams', type=int, default=2, help='engines / HIP streams the chunks alternate over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-rows256', action='store_true', help='skip the secondary 256-row single-plan measurement')
@@ -949,7 +980,7 @@ def main():
         try:
             out['hbm_bound_kernel_classes'] = dict(
                 hbm_bound_classes(eng, s), _note='BASELINE.md §3: achieved_hbm = algorithmic bytes (inputs + outputs of the op, fp32) / '
-                'HIP-event kernel time / 8 TB/s, per memory-bound kernel class of one 512-row chunk (forward + backward plan, one stream)')
+                f'HIP-event kernel time / 8 TB/s, per memory-bound kernel class of one {args.chunk_rows}-row chunk (forward + backward plan, one stream)')
         except Exception as ex:
             out['hbm_bound_kernel_classes'] = {'_note': f'failed: {type(ex).__name__}: {ex}'}
         if world == 1 and not args.no_secondary and not args.stub_engine:
@@ -1027,7 +1058,7 @@ def main():
                 log('cpu baseline (oracle on host cores) ...')
                 def parity(xc, epsc, lc, gc):
                     # the same 128 rows on the HIP path (oracle as the checker): logits and input gradient of the CE loss.  The
-                    # headline's 512-row plans run 32 decoder cells per direction as fused ga_dec_cell launches; at 128 rows the
+                    # headline's chunk plans run 32 decoder cells per direction as fused ga_dec_cell launches; at 128 rows the
                     # engine would pick the three unfused launches (fewer than 160 workgroups), so the gate is forced here: the
                     # CHECKED path is the TIMED path (`fused_cells` says how many of the replay's launches were ga_dec_cell)
                     from gen_adversarial_amd.engine import Engine
@@ -1057,8 +1088,8 @@ def main():
                         'fused_cells': int(n_fused),
                         'headline_fused_cells': int(headline_fused),
                         'note': 'same inputs and latent noise as the cpu_baseline sample, replayed with the fused decoder cells forced '
-                                'on (the kernels the timed 512-row plans select); tolerance of the path: 1e-3 on logits'}
-                out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)
+                                'on (the kernels the timed chunk plans select); tolerance of the path: 1e-3 on logits'}
+                out['cpu_baseline'] = cpu_baseline(model, 4 * args.eot, args.eot, check=parity)      # 128 rows: ~16 s of oracle time on 16 threads
                 log('cpu baseline done')
                 if args.robust_acc_images > 0:
                     # robust accuracy under the reference's APGD-CE, HIP vs oracle, every draw pinned, with the paired 95 % interval of

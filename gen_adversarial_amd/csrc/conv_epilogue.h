@@ -113,12 +113,12 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, f
         const int q = tid % QL, rr = tid / QL;
         const int co = n0 + 4 * q;
         const bool mine = co < d.Cout;
-        // The epilogue's global operands (act' input, addends) of batch b + 1 are requested BEFORE the arithmetic and the stores of
-        // batch b, and those of batch 0 before the accumulators go through LDS: one exposed memory round trip per workgroup instead
-        // of one per batch (r04; the loads of a batch used to be issued only after the previous batch's stores).  Two register sets,
-        // statically indexed (the batch loop is unrolled).  In-place accumulation (addend == y) is safe: a thread reads and writes
-        // the SAME elements, and each element belongs to one thread.
-        floatx4 u[2][NB], a1[2][NB], a2[2][NB];
+        // Each batch of NB rows requests its global operands (act' input, addends), then does its arithmetic and stores.  (r04: a
+        // software-pipelined form — batch b + 1's operands requested before batch b's arithmetic, batch 0's before the LDS
+        // transposition, two register sets, the batch loop unrolled — measured 0 - 5 % SLOWER per launch on forward and backward
+        // 3x3 shapes in interleaved A/B runs on one box, gpurun_out/r04_ab_epi.log: the co-resident workgroup already covers the
+        // round trips, the unrolled code only costs registers and instruction cache.  Not kept.)
+        floatx4 u[1][NB], a1[1][NB], a2[1][NB];
         auto issue = [&](const int set, const int rb0) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -147,19 +147,18 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, f
                 ds4 = *reinterpret_cast<const floatx4*>(d.dact_scale + co);
                 dt4 = *reinterpret_cast<const floatx4*>(d.dact_shift + co);
             }
-            issue(0, rr);
         }
         acc_walk(acc, lane, [&](const int row, const int col, const float v) {
             Cs[(wm * TM * 32 + row) * LDC + wn * TN * 32 + col] = v;
         });
         __syncthreads();
         if (mine) {
-#pragma unroll
+#pragma unroll 1
             for (int it = 0; it < NIT; ++it) {
-                const int rb0 = rr + it * ROWS * NB, set = it & 1;
+                const int rb0 = rr + it * ROWS * NB, set = 0;
                 floatx4 v[NB];
                 bool ok[NB];
-                if (!ws && it + 1 < NIT) issue(set ^ 1, rb0 + ROWS * NB);
+                if (!ws) issue(0, rb0);
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     const int r = rb0 + k * ROWS;

@@ -382,6 +382,12 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
     // of 18 registers — two conflict-free LDS reads per slot and chunk, and the kernel fits its 256 registers without scratch
     int* sl_g = reinterpret_cast<int*>(smem + tab_off);
     unsigned short* sl_p = reinterpret_cast<unsigned short*>(sl_g + rp * 256);
+    // split-K over channel chunks (needed here already: the FIRST chunk's patch loads leave from the slot loop below, so that their
+    // memory round trip runs under the rest of the setup — prologue table, fragment addresses — instead of after it; r04)
+    const int splits = gridDim.y, split = blockIdx.y;
+    const int cper = (nkc + splits - 1) / splits;
+    const int cb = split * cper, ce = min(nkc, cb + cper);
+    floatx4 rpat[RPMAX];
 #pragma unroll
     for (int j = 0; j < RPMAX; ++j) {
         if (j < rp) {
@@ -395,6 +401,7 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
                 const int n = n_first + img, hi = y0 - 1 + py, wi = x0 + px - 1;
                 if (n < d.N && hi >= 0 && hi < d.Hi && wi >= 0 && wi < d.Wi) off = ((n * d.Hi + hi) * d.Wi + wi) * d.ldx * 4 + c4 * 16;
             }
+            if (cb < ce) rpat[j] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, cb * HK * 4, 0));
             sl_g[j * 256 + tid] = off;
             sl_p[j * 256 + tid] = (unsigned short)pl;
         }
@@ -433,7 +440,6 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
         halfoff = img * g.IS + y * g.RS + x * LDHr;
     }
 
-    floatx4 rpat[RPMAX];
     auto issue_patch = [&](const int chunk) __attribute__((always_inline)) {
         const int soff = chunk * HK * 4;
 #pragma unroll
@@ -463,7 +469,7 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
                     }
                 }
                 if (AFF == 2) {
-                    const int img = fd_div(4 * pl, g.fd_is);
+                    const int img = pl != 0xffff ? fd_div(4 * pl, g.fd_is) : 0;        // (no such patch pixel: any table row, the value is dropped)
                     const float* tp = ptab + img * C + chunk * HK + 4 * c4;
                     v = v * *reinterpret_cast<const floatx4*>(tp) + *reinterpret_cast<const floatx4*>(tp + TI * C);
                 }
@@ -559,14 +565,9 @@ conv_halo3_bd_kernel(const ga_conv_desc d, const int tilesN, const int M, const 
         }
     };
 
-    const int splits = gridDim.y, split = blockIdx.y;
-    const int cper = (nkc + splits - 1) / splits;
-    const int cb = split * cper, ce = min(nkc, cb + cper);
-
     GA_HSTAMP(1)
     if (cb < ce) {
-        issue_patch(cb);
-        load_B(bcur, cb, 0);
+        load_B(bcur, cb, 0);                                 // (the first chunk's patch loads are already in flight: slot loop above)
         finish_patch(cb, 0);
         if (cb + 1 < ce) issue_patch(cb + 1);
     }
@@ -785,6 +786,9 @@ static int launch_halo_bd(const ga_conv_desc& d, hipStream_t stream, int vec_out
     if (lds > 80 * 1024) return GA_E_UNSUPPORTED;                       // (two workgroups per CU are the kernel's launch bounds)
     const size_t lds_c = (size_t)BM * (BN + 4) * sizeof(float);
     if (lds_c > lds) lds = lds_c;
+    // (r04 experiment, dropped: asking for > 80 KB of LDS so that a launch takes ONE workgroup slot per CU and the second slot goes to
+    // the other stream's kernel — out of phase, so that one's setup / epilogue would overlap the other's K loop: 5,579 against 5,949 -
+    // 5,967 rows/s on the same box, gpurun_out/r04_ab_epi.log: a lone conv launch then runs at half occupancy)
     const dim3 grid(tilesM * tilesN, splits);
 #define GA_HBD(A, C) launch_halo_bd_inst<A, C, 9, M16>(d, stream, grid, lds, tilesN, M, nkc, vec_out, g, dbuf, tab_off)
     if (g.P > 9 * 32) return GA_E_UNSUPPORTED;                          // row-segment tiles of wide images: the LDS-staged kernel

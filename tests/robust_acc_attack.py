@@ -133,3 +133,88 @@ def robust_accuracy_under_attack(device='cuda:0', n_images=256, eot=2, n_iter=5,
                     'reduced NVAE + VGG defender behind load(args); start noise and per-call latent noise pinned and equal on both sides; '
                     'labels = the oracle\'s clean prediction; verdict = the attack\'s own success flag; paired 95 % interval on the '
                     'difference of the two robust accuracies'}
+
+
+class _EngineFn(torch.autograd.Function):
+    """EoT-mean logits of a bare Engine as a differentiable function of the image batch (the latent noise is whatever the caller put
+    into eng.eps: pinned for the whole run)"""
+
+    @staticmethod
+    def forward(ctx, x, eng, eot):
+        eng.x_in.copy_(x.detach())
+        eng.forward()
+        ctx.eng, ctx.eot, ctx.x = eng, eot, x.detach().clone()
+        return eng.logits.view(x.shape[0], eot, -1).mean(dim=1).clone()
+
+    @staticmethod
+    def backward(ctx, dl):
+        eng, eot = ctx.eng, ctx.eot
+        eng.x_in.copy_(ctx.x)
+        eng.forward()                                          # (another forward may have run on this engine since)
+        eng.dlogits.view(dl.shape[0], eot, -1).copy_((dl / eot).unsqueeze(1).expand(-1, eot, -1))
+        eng.backward()
+        return eng.dx.clone(), None, None
+
+
+class _EngineNet(torch.nn.Module):
+    def __init__(self, eng, eot):
+        super().__init__()
+        self.eng, self.eot = eng, eot
+
+    def forward(self, x):
+        return _EngineFn.apply(x, self.eng, self.eot)
+
+
+def fullsize_same_input_verdicts(device='cuda:0', n_images=8, eot=2, n_iter=3, bound=2.0, seed=0, threads=None):
+    """VERDICT r03 "next round" #3, last clause: same-input verdicts on the FULL-SIZE model (the assumed NVAE configuration of the
+    bench + VGG-11) for a small N.  The HIP engine produces adversarial examples with the reference's APGD-CE (pinned latent noise,
+    pinned start noise); the CPU oracle then judges the clean and the adversarial images under the same noise, as does the engine:
+    verdicts (argmax of the EoT-mean logits) and logits are compared on identical inputs."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import build_model
+    from gen_adversarial_amd.attacks.l2_attacks import APGDAttack
+    from gen_adversarial_amd.nvae_spec import ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION, build_spec
+    from oracle import defender_oracle as D
+    if threads is None:
+        threads = min(16, len(os.sched_getaffinity(0)))
+    torch.set_num_threads(threads)
+    rows = n_images * eot
+    eng, (sd, vsd, vspec, alphas) = build_model(device, rows, eot, seed=0)
+    spec = build_spec(ASSUMED_NVAE_CONFIG, ASSUMED_NVAE_RESOLUTION)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n_images, 3, 64, 64, generator=g)
+    eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=g) for gs in spec.groups]
+    init = torch.randn(n_images, 3, 64, 64, generator=g)
+    for dst, src in zip(eng.eps, eps):
+        dst.copy_(src.to(device))
+    net = _EngineNet(eng, eot)
+
+    def oracle(imgs):
+        with torch.no_grad():
+            lg, _ = D.nvae_defender(sd, spec, vsd, vspec, imgs.repeat_interleave(eot, dim=0), alphas, eps, torch.ones(rows, 3, 64, 64), 0.0)
+        return lg.view(n_images, eot, -1).mean(dim=1)
+    t = time.time()
+    lo_clean = oracle(x)
+    labels = lo_clean.argmax(dim=1)
+    with torch.no_grad():
+        lh_clean = net(x.to(device)).cpu()
+    t_h = time.time()
+    ok, b, adv = APGDAttack(n_iter=n_iter, rho=0.75, max_bound=bound, ce_loss=True)(x.to(device), labels.to(device), net, init_noise=init.to(device))
+    torch.cuda.synchronize()
+    t_h = time.time() - t_h
+    with torch.no_grad():
+        lh_adv = net(adv).cpu()
+    lo_adv = oracle(adv.cpu())
+    t_all = time.time() - t
+    vh = torch.cat([lh_clean.argmax(dim=1) == labels, lh_adv.argmax(dim=1) == labels])
+    vo = torch.cat([lo_clean.argmax(dim=1) == labels, lo_adv.argmax(dim=1) == labels])
+    top2 = torch.cat([lo_clean, lo_adv]).topk(2, dim=1).values
+    return {'model': 'full size (assumed NVAE configuration C=32, 3x8 groups, 20 latents + VGG-11), random weights',
+            'images': n_images, 'eot': eot, 'attack': f'apgd-ce, {n_iter} iterations, L2 bound {bound}, run on the HIP engine',
+            'verdict_pairs': int(vh.numel()), 'verdicts_differing': int((vh != vo).sum()),
+            'robust_acc_hip_judged': float(vh[n_images:].float().mean()), 'robust_acc_oracle_judged': float(vo[n_images:].float().mean()),
+            'max_abs_logit_err_clean': float((lh_clean - lo_clean).abs().max()), 'max_abs_logit_err_adversarial': float((lh_adv - lo_adv).abs().max()),
+            'smallest_oracle_decision_margin': float((top2[:, 0] - top2[:, 1]).min()),
+            'mean_l2_of_adversarial': float(torch.as_tensor(b).float().mean()), 'hip_attack_seconds': t_h, 'total_seconds': t_all,
+            'cpu_threads': threads}

@@ -105,9 +105,12 @@ class Recorder(torch.nn.Module):
         return out
 
 
-def _replay(name, log, model):
+def _replay(name, log, model, oracle, max_exact=12):
     """every recorded query answered by the HIP defender"""
-    e_l = e_g = frac = 0.0
+    from gradcheck import assert_grad_given_engine_decisions
+    e_l = e_g = 0.0
+    total = sum(len(q['back']) for q in log)
+    stride = max(1, -(-total // max_exact))                     # at most `max_exact` oracle replays per run, evenly spread
     n_back = 0
     for q in log:
         xd = q['x'].to(DEV).requires_grad_(bool(q['back']))
@@ -115,14 +118,15 @@ def _replay(name, log, model):
         e_l = max(e_l, (out.detach().cpu() - q['logits']).abs().max().item())
         for cot, gx in q['back']:
             (g,) = torch.autograd.grad(out, [xd], cot.to(DEV), retain_graph=True)
-            diff = g.cpu() - gx
-            e_g = max(e_g, (diff.norm() / gx.norm().clamp_min(1e-30)).item())
-            frac = max(frac, (diff.abs() > 1e-3 * gx.abs().max()).float().mean().item())
+            e_g = max(e_g, ((g.cpu() - gx).norm() / gx.norm().clamp_min(1e-30)).item())
+            if n_back % stride == 0:        # on EVERY element, given the engine's ReLU / max-pool decisions (tests/gradcheck.py)
+                eng = model.model._engine(xd.shape[0] * EOT, EOT)
+                assert_grad_given_engine_decisions(eng, lambda t: (oracle(t) * cot).sum(), q['x'], g, 1e-3,
+                                                   f'{name} replay, input gradient of backward pass {n_back + 1} of {total}', min_matched=8)
             n_back += 1
-    print(f'   {name} replay: {len(log)} queries, {n_back} backward passes: logits {e_l:.1e}, gradients relL2 {e_g:.1e}, '
-          f'elements beyond 1e-3 of max |g|: {100 * frac:.3f} %')
+    print(f'   {name} replay: {len(log)} queries, {n_back} backward passes: logits {e_l:.1e}; gradients against the recorded ones WITHOUT '
+          f'decision replay: worst relative L2 {e_g:.1e} (a single flipped near-tie decision moves it: reported, not asserted)')
     assert e_l < 1e-3, (name, e_l)
-    assert e_g < 2e-2 and frac < 0.01, (name, e_g, frac)
 
 
 def _compare(name, x, res_hip, res_cpu, oracle, labels):
@@ -157,7 +161,7 @@ def _compare(name, x, res_hip, res_cpu, oracle, labels):
 def _both(name, mk, x, labels, model, oracle, **kw):
     rec = Recorder(oracle)
     res_cpu = mk()(x, labels, rec, **kw)
-    _replay(name, rec.log, model)
+    _replay(name, rec.log, model, oracle)
     res_hip = mk()(x.to(DEV), labels.to(DEV), model, **{k: v.to(DEV) for k, v in kw.items()})
     _compare(name, x, res_hip, res_cpu, oracle, labels)
     return res_hip, res_cpu
@@ -193,7 +197,7 @@ def test_fab_on_hip_defender_equals_oracle(pair):
     model, oracle = pair
     x = _images(1, 300)
     labels, _ = _labels(oracle, x)
-    _both('FAB', lambda: FABAttack(n_iter=6, alpha_max=0.1, eta=1.05, beta=0.9), x, labels, model, oracle)
+    _both('FAB', lambda: FABAttack(n_iter=8, alpha_max=0.1, eta=1.05, beta=0.9), x, labels, model, oracle)      # (succeeds at iteration 8)
 
 
 def test_cw_on_hip_defender_equals_oracle(pair):
@@ -210,13 +214,15 @@ def test_cw_on_hip_defender_equals_oracle(pair):
         n = real(image.cpu())
         draws.append(n)
         return n
-    mk = lambda: CW(c=16., kappa=0.05, steps=10, lr=5e-3, n_restarts=2)   # noqa: E731
+    # c and lr far above the reference's (c = 16, lr = 5e-3: 1024 steps x 8 restarts there) so that a 12-step run crosses the boundary
+    # of this random-weight defender (L2 ~ 12): a run that fails returns the clean image on both sides and compares nothing
+    mk = lambda: CW(c=1000., kappa=0.05, steps=12, lr=1e-1, n_restarts=2)   # noqa: E731
     try:
         A._per_image_randn = recorded
         torch.manual_seed(3)
         rec = Recorder(oracle)
         res_cpu = mk()(x, labels, rec)
-        _replay('C&W', rec.log, model)
+        _replay('C&W', rec.log, model, oracle)
         it = iter(list(draws))
         A._per_image_randn = lambda image: next(it).to(image.device)
         res_hip = mk()(x.to(DEV), labels.to(DEV), model)

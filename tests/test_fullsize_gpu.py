@@ -260,18 +260,18 @@ def test_halo_fused_post_processing_cells_equal_the_unfused_launches(model, monk
         assert e < 2e-5, what
 
 
-def test_bench_shape_512_rows_fused_plan_vs_unfused_plan_and_oracle(model, monkeypatch):
-    """The shape bench.py times (512-row chunk plans: 16 images x EoT 32): at 512 / 256 workgroups the engine
+def test_bench_shape_1024_rows_fused_plan_vs_unfused_plan_and_oracle(model, monkeypatch):
+    """The shape bench.py times (1024-row chunk plans since r04: 32 images x EoT 32): at 1024 / 512 workgroups the engine
     selects ga_dec_cell for 32 cells per direction BY ITSELF.  (a) That plan against the same plan built from the unfused launches,
     both with the tune table bench.py uses: equal to rounding (1e-5 of the tensor's scale; bitwise when the table gives the unfused
     1x1 convs no split-K — reported, not asserted: bitwise equality of the KERNELS is the 8-row test above, which pins the kernels
     instead of relying on the table's contents).  (b) Rows 0..3 of the fused plan against the CPU oracle on those four
-    rows (rows are independent; the cotangent is zero on the other 508): logits / purified at 1e-3, the input gradient on every
+    rows (rows are independent; the cotangent is zero on the other 1020): logits / purified at 1e-3, the input gradient on every
     element given the engine's ReLU / max-pool decisions."""
     from gen_adversarial_amd import _lib as L
     from oracle import defender_oracle as D
     m, spec = model, model['spec']
-    rows, rep, k = 512, 32, 4
+    rows, rep, k = 1024, 32, 4
     gen = torch.Generator().manual_seed(31)
     imgs = torch.rand(rows // rep, 3, 64, 64, generator=gen)
     eps = [torch.randn(rows, spec.num_latent, gs.res, gs.res, generator=gen) for gs in spec.groups]
@@ -301,17 +301,17 @@ def test_bench_shape_512_rows_fused_plan_vs_unfused_plan_and_oracle(model, monke
             nz = torch.randn(k, 3, 64, 64, generator=gen)          # drawn and scaled by eps = 0 (abstract_models.py:132-138)
             lg, pur = D.nvae_defender(m['sd'], spec, m['vsd'], m['vspec'], x0.repeat_interleave(k, dim=0), m['alphas'], e4, nz, 0.0)
             e_l, e_p = err(eng.logits[:k], lg), err(eng.purified[:k], pur)
-            print(f'512-row fused plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} purified {e_p:.2e}')
+            print(f'1024-row fused plan vs oracle, rows 0..{k - 1}: logits {e_l:.2e} purified {e_p:.2e}')
             assert e_l < TOL and e_p < TOL
             from gradcheck import assert_grad_given_engine_decisions
             assert_grad_given_engine_decisions(
                 eng, lambda t: (D.nvae_defender(m['sd'], spec, m['vsd'], m['vspec'], t.repeat_interleave(k, dim=0), m['alphas'], e4,
                                                 nz, 0.0)[0] * cot[:k]).sum(),
-                imgs[:1], eng.dx[:1], 1e-3, 'input gradient of rows 0..3 inside the fused 512-row plan', min_matched=8, rows=slice(0, k))
+                imgs[:1], eng.dx[:1], 1e-3, 'input gradient of rows 0..3 inside the fused 1024-row plan', min_matched=8, rows=slice(0, k))
             assert float(eng.dx[1:].abs().max()) == 0.0           # images whose rows carry no cotangent get no gradient
         del eng
         torch.cuda.empty_cache()
     for a, b, what in zip(out[True], out[False], ('purified', 'logits', 'dense input gradient', 'sparse input gradient')):
         e = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
-        print(f'fused vs unfused 512-row plans, {what}: max |diff| {e:.1e} of the scale, bitwise {torch.equal(a, b)}')
-        assert e < 1e-5, f'fused and unfused 512-row plans differ in the {what}'
+        print(f'fused vs unfused 1024-row plans, {what}: max |diff| {e:.1e} of the scale, bitwise {torch.equal(a, b)}')
+        assert e < 1e-5, f'fused and unfused 1024-row plans differ in the {what}'
