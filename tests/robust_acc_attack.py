@@ -41,7 +41,9 @@ class _Scheduled(torch.nn.Module):
 
 
 def robust_accuracy_under_attack(device='cuda:0', n_images=256, eot=2, n_iter=5, bound=2.0, seed=0, chunk_images=64, threads=None,
-                                 tmpdir=None, progress=False):
+                                 tmpdir=None, progress=False, model_seed=0):
+    """seed: images, start noise and latent draws; model_seed: the random weights (runs that are pooled share the model: another
+    random model has other margins — the one with model_seed 1 is robust on every image at this bound, which adds nothing)"""
     import tempfile
     from argparse import Namespace
     import yaml
@@ -60,8 +62,8 @@ def robust_accuracy_under_attack(device='cuda:0', n_images=256, eot=2, n_iter=5,
     ng = len(spec.groups)
     alphas = [i / (ng - 1) for i in range(ng)]
     d = tmpdir or tempfile.mkdtemp(prefix='ga_racc_')
-    ck = nvae_checkpoint(CFG, RES, seed=seed + 5)
-    vsd = init_vgg_state_dict(100, 16, seed=seed + 6)
+    ck = nvae_checkpoint(CFG, RES, seed=model_seed + 5)
+    vsd = init_vgg_state_dict(100, 16, seed=model_seed + 6)
     torch.save(ck, os.path.join(d, 'nvae.pt'))
     torch.save({'state_dict': vsd}, os.path.join(d, 'vgg.pt'))
     with open(os.path.join(d, 'cfg.yaml'), 'w') as f:

@@ -28,7 +28,8 @@ if len(sys.argv) > 1 and sys.argv[1] == 'apgd':
     sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == 'pool':
-    # pool several apgd runs (different seeds = different models, images and draws): the paired interval on the pooled verdict pairs
+    # pool several apgd runs on the SAME random model (model_seed 0) with different data seeds (images, start noise, latent draws):
+    # the paired interval on the pooled verdict pairs
     import math
     runs = [json.loads(open(f).read().strip().splitlines()[-1]) for f in sys.argv[2:]]
     n = sum(r['images'] for r in runs)
@@ -45,7 +46,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'pool':
                       'same_input_verdicts_differing': sum(r['same_input_verdicts_differing'] for r in runs),
                       'same_input_verdict_pairs': sum(r['same_input_verdict_pairs'] for r in runs),
                       'oracle_seconds': sum(r['oracle_seconds'] for r in runs), 'hip_seconds': sum(r['hip_seconds'] for r in runs),
-                      'what': 'pooled over runs with different seeds (model weights, images, noise): ' + runs[0]['what']}))
+                      'what': 'pooled over runs on the same random model with different data seeds (images, start noise, latent draws): ' + runs[0]['what']}))
     sys.exit(0)
 
 if len(sys.argv) > 1 and sys.argv[1] == 'fullsize':
