@@ -93,10 +93,16 @@ __device__ __forceinline__ void acc_walk(floatx4 (&acc)[TM2][TN2], const int lan
             for (int r = 0; r < 4; ++r) f(i * 16 + 4 * lq + r, j * 16 + lc, acc[i][j][r]);
 }
 
-// acc: per-wave accumulators (either form above); smem: >= BM*(BN+4) floats, free to overwrite
+// acc: per-wave accumulators (either form above); smem: >= BM*(BN+4) floats, free to overwrite.
+// Tile rows -> output pixels: row r of the tile is pixel m0 + r (tiles that are runs of the [N, Ho, Wo] pixel index: the default,
+// tw_shift = 31) or, for 2-D tiles of 2^tw_shift columns (conv_thin3: 8 x 16 pixel tiles of a wide image), pixel
+// m0 + (r >> tw_shift) * row_stride + (r & (2^tw_shift - 1)) with m0 the tile's top-left pixel and row_stride = Wo.
 template <int WM, int WN, int TM, int TN, class ACC>
 __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, float* smem, const int m0,
-                                              const int n0, const int M, const int vec_out, const int splits, const int split) {
+                                              const int n0, const int M, const int vec_out, const int splits, const int split,
+                                              const int tw_shift = 31, const int row_stride = 0) {
+    const int tw_mask = (int)((1u << tw_shift) - 1u);
+    auto mrow = [&](const int r) __attribute__((always_inline)) { return m0 + (r >> tw_shift) * row_stride + (r & tw_mask); };
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDC = BN + 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,19 +129,20 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, f
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int r = rb0 + k * ROWS;
-                const bool ok = m0 + r < M;
+                const int mr = mrow(r);
+                const bool ok = mr < M;
                 if (d.dact_x) {
-                    const size_t m = ok ? dact_row(d, (size_t)(m0 + r), HoWo) : 0;
+                    const size_t m = ok ? dact_row(d, (size_t)mr, HoWo) : 0;
                     u[set][k] = *reinterpret_cast<const floatx4*>(d.dact_x + m * d.lddact + co);
                 }
                 if (d.addend) {
-                    size_t m = ok ? (size_t)(m0 + r) : 0;
+                    size_t m = ok ? (size_t)mr : 0;
                     if (d.addend_bcast_n) m = m % HoWo;
                     if (d.addend_rep > 1) m = ((m / HoWo) / d.addend_rep) * HoWo + (m % HoWo);
                     a1[set][k] = *reinterpret_cast<const floatx4*>(d.addend + m * d.ldadd + co);
                 }
                 if (d.addend2) {
-                    const size_t m = ok ? (size_t)(m0 + r) : 0;
+                    const size_t m = ok ? (size_t)mr : 0;
                     a2[set][k] = *reinterpret_cast<const floatx4*>(d.addend2 + m * d.ldadd2 + co);
                 }
             }
@@ -162,13 +169,13 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, f
 #pragma unroll
                 for (int k = 0; k < NB; ++k) {
                     const int r = rb0 + k * ROWS;
-                    ok[k] = m0 + r < M;
+                    ok[k] = mrow(r) < M;
                     v[k] = *reinterpret_cast<const floatx4*>(Cs + r * LDC + 4 * q);
                 }
                 if (ws) {
 #pragma unroll
                     for (int k = 0; k < NB; ++k)
-                        if (ok[k]) *reinterpret_cast<floatx4*>(ws + (size_t)(m0 + rb0 + k * ROWS) * d.Cout + co) = v[k];
+                        if (ok[k]) *reinterpret_cast<floatx4*>(ws + (size_t)mrow(rb0 + k * ROWS) * d.Cout + co) = v[k];
                     continue;
                 }
 #pragma unroll
@@ -198,13 +205,13 @@ __device__ __forceinline__ void conv_epilogue(const ga_conv_desc& d, ACC& acc, f
                         }
                     }
                     if (d.addend2) o += a2[set][k];
-                    if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)(m0 + rb0 + k * ROWS) * d.ldy + co) = o;
+                    if (ok[k]) *reinterpret_cast<floatx4*>(d.y + (size_t)mrow(rb0 + k * ROWS) * d.ldy + co) = o;
                 }
             }
         }
     } else {
         acc_walk(acc, lane, [&](const int row, const int col, const float v) {
-            const int co = n0 + wn * TN * 32 + col, m = m0 + wm * TM * 32 + row;
+            const int co = n0 + wn * TN * 32 + col, m = mrow(wm * TM * 32 + row);
             if (co < d.Cout && m < M) {
                 if (ws) ws[(size_t)m * d.Cout + co] = v;
                 else epilogue1(d, m, co, v, HoWo);

@@ -426,6 +426,8 @@ int conv_bf3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int v
 int conv_bf3_supports(const ga_conv_desc& d);
 int conv_halo3_dispatch(const ga_conv_desc& d, hipStream_t stream, int tile, int vec_out, int splits);  // conv_halo3.hip
 int conv_halo3_supports(const ga_conv_desc& d);
+int conv_thin3_dispatch(const ga_conv_desc& d, hipStream_t stream, int vec_out, int splits);             // conv_thin3.hip
+int conv_thin3_supports(const ga_conv_desc& d);
 
 }  // namespace ga
 
@@ -545,7 +547,10 @@ extern "C" int ga_conv2d(const ga_conv_desc* dp, void* stream_) {
                      d.KH * d.KW <= 32 && k.x_bytes > 0 && k.w_bytes > 0 && (d.C2 == 0 || k.x2_bytes > 0) &&
                      aligned16(d.w_hi) && aligned16(d.w_lo) && conv_bf3_supports(d);
     int rc;
-    if (tile >= 5 && tile <= 10) {      // halo-staged 3x3 (explicit request only: the tune table names it per shape)
+    if (tile == 11) {                   // persistent weights-resident 3x3 for 32 input channels (explicit request only; w_frag in the thin order)
+        if (!(bf3 && vec_out && conv_thin3_supports(d))) return GA_E_UNSUPPORTED;
+        rc = conv_thin3_dispatch(k, stream, vec_out, splits);
+    } else if (tile >= 5 && tile <= 10) {      // halo-staged 3x3 (explicit request only: the tune table names it per shape)
         if (!(bf3 && vec_out && conv_halo3_supports(d))) return GA_E_UNSUPPORTED;
         rc = conv_halo3_dispatch(k, stream, tile, vec_out, splits);
     } else if (bf3) {

@@ -98,6 +98,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         self._sampler_descs = []             # (desc, latent index): alphas can be changed without rebuilding
         self._keep = []                      # weights etc.
         self._frag_ok = {}                   # id(ConvDesc) -> weight tensor of the convs that may run on tile 8
+        self._thin_ok = {}                   # ... on tile 11
         self.fwd = L.Plan()
         self.bwd = L.Plan()
         self._bwd_steps = []                 # closures emitting backward ops, replayed in reverse
@@ -125,7 +126,7 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         self.share_encoder = bool(share_encoder) and rep > 1 and self.noise_eps == 0.0
         self.enc_rows = rows // rep if self.share_encoder else rows
         self.need_backward, self.image_s2d, self.cot_rep = need_backward, False, 1
-        self.bytes, self.acts, self.version, self._sampler_descs, self._keep, self._frag_ok = 0, {}, 0, [], [], {}
+        self.bytes, self.acts, self.version, self._sampler_descs, self._keep, self._frag_ok, self._thin_ok = 0, {}, 0, [], [], {}, {}
         self.fwd, self.bwd, self._bwd_steps, self._scratch = L.Plan(), L.Plan(), [], {}
         self.eps, self.purified, self.dpurified, self._purified_grad_nhwc = [], None, None, None
         return self
@@ -177,6 +178,9 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
                 # LAZILY — by apply_tuning for the descs whose tuned tile is 8, by autotune for its candidates — not for every
                 # eligible 3x3 weight (52 of 1594 tuned shapes select tile 8; an eager copy doubled the split-weight memory)
                 self._frag_ok[id(d)] = w
+            if (kh, kw, sn, sd, pad) == (3, 3, 1, 1, 1) and x2 is None and (cin or x.shape[3]) == 32 and x.shape[1] % 8 == 0 \
+                    and x.shape[2] % 16 == 0 and w.dim() == 2 and w.shape[1] == 9 * 32:
+                self._thin_ok[id(d)] = w                    # tile 11 (conv_thin3): persistent weights-resident kernel, its own fragment order
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
         No, Ho, Wo, Cy = y.shape
         d.y, d.ldy = _ptr(y), (ldy or Cy)
@@ -435,6 +439,8 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
                 tile, splits = 0, 1
             if tile == 8 and not self._want_frag(d):    # conv_key does not encode pad / Wo / weight layout: a desc that shares the key of
                 tile = 5                                # a tile-8 entry without being eligible runs tile 5 (bitwise the same result)
+            if tile == 11 and (splits > 1 or not self._want_thin(d)):
+                tile, splits = 7, 1                     # (likewise: tile 7 gives tile 11's bits)
             d.tile, d.splits = int(tile), int(splits)
             d.ws, d.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)
             if not use_bf3:                      # this shape is faster on the exact fp32 kernel (small K or Cout)
@@ -443,13 +449,19 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         self.bwd.finalize()
 
     def _want_frag(self, d) -> bool:
-        """make sure d.w_frag exists (tile 8); False when this conv cannot run on tile 8"""
-        if d.w_frag:
-            return True
+        """point d.w_frag at the tile-8 fragment copy (built on first use); False when this conv cannot run on tile 8"""
         w = self._frag_ok.get(id(d))
         if w is None or self.dry_run:
             return False
         d.w_frag = _ptr(self.store.frag3(w))
+        return True
+
+    def _want_thin(self, d) -> bool:
+        """point d.w_frag at the tile-11 fragment copy; False when this conv cannot run on tile 11"""
+        w = self._thin_ok.get(id(d))
+        if w is None or self.dry_run:
+            return False
+        d.w_frag = _ptr(self.store.frag_thin(w))
         return True
 
     def autotune(self, cache: Optional[dict] = None, reps: int = 3, save: Optional[str] = None, verbose: bool = False) -> dict:
@@ -469,8 +481,10 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             halo = (5, 6, 7) if (d.w_hi and d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0) else ()
             if halo and self._want_frag(d):
                 halo = halo + (8,)
-            for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + (halo if m_ else ())]:
-                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32), 8: (128, 128)}[tile]
+            thin = (11,) if (d.w_hi and id(d) in self._thin_ok) else ()
+            for use_bf3, tile in [(m_, t_) for m_ in modes for t_ in (1, 2, 3, 4) + ((halo + thin) if m_ else ())]:
+                bm, bn = {1: (128, 128), 2: (128, 64), 3: (64, 64), 4: (128, 32), 5: (128, 128), 6: (128, 64), 7: (128, 32), 8: (128, 128),
+                          11: (128, 32)}[tile]
                 if bn >= 2 * max(32, d.Cout) and tile not in (4, 7):
                     continue
                 blocks = -(-M // bm) * -(-d.Cout // bn)
@@ -479,8 +493,14 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
                         continue
                     if tile >= 5 and splits > d.C1 // 32:          # the halo kernel splits K over 32-channel chunks
                         continue
+                    if tile == 11 and splits > 1:
+                        continue
                     t = L.ConvDesc.from_buffer_copy(d)
                     t.tile, t.splits = tile, splits
+                    if tile == 11:
+                        t.w_frag = _ptr(self.store.frag_thin(self._thin_ok[id(d)]))
+                    elif tile == 8:
+                        t.w_frag = _ptr(self.store.frag3(self._frag_ok[id(d)]))
                     if not use_bf3:
                         t.w_hi, t.w_lo = None, None
                     t.ws, t.ws_floats = (_ptr(self.ws), WS_FLOATS) if splits > 1 else (None, 0)

@@ -85,7 +85,9 @@ typedef struct ga_conv_desc {
                                               5 = 128x128, 6 = 128x64, 7 = 128x32 on the halo-staged 3x3 kernel (3x3, stride 1,
                                               pad 1, C1 % 32 == 0, 128 % Wo == 0 or Wo % 128 == 0, w_hi/w_lo given;
                                               GA_E_UNSUPPORTED otherwise); 8 = 128x128 on the same kernel with the weight
-                                              fragments read from global memory (w_frag given, 128 % Wo == 0) */
+                                              fragments read from global memory (w_frag given, 128 % Wo == 0);
+                                              11 = persistent weights-resident 3x3 for C1 == 32 on 8 x 16 pixel tiles (3x3, stride 1,
+                                              pad 1, Ho % 8 == 0, Wo % 16 == 0, no split-K, w_frag given in the tile-11 order below) */
     int splits;                            /* split-K factor (<=1: none); needs ws */
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
     long ws_floats;
@@ -102,7 +104,11 @@ typedef struct ga_conv_desc {
                                               [ceil(Cout/128)][C1/32][9 taps][4 waves][2 k steps][hi | lo][64 lanes][8]: element e of
                                               lane l = W[128 t + 32 wave + (l & 31)][tap * C1 + 32 chunk + 16 kstep + 8 (l >> 5) + e]
                                               (rows >= Cout zero).  The halo kernel then reads its B fragments from global memory:
-                                              no weight staging through LDS, one barrier per 32-channel chunk */
+                                              no weight staging through LDS, one barrier per 32-channel chunk.
+                                              Tile 11 (C1 == 32) takes another order of the same weights:
+                                              [ceil(Cout/32)][9 taps][2 k steps][hi | lo][64 lanes][8], element e of lane l =
+                                              W[32 t + (l & 31)][tap * 32 + 16 kstep + 8 (l >> 5) + e] (rows >= Cout zero): each workgroup
+                                              keeps one 36-KB block in LDS for its lifetime */
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 
@@ -590,7 +596,7 @@ long ga_debug_set_conv_row_limit(long bytes);
 const char* ga_last_hip_error(void);
 /* GA_ABI_VERSION is bumped with EVERY change of a descriptor's layout or meaning (a field added, a reserved field put to use) and
  * with every entry point added; the binding (gen_adversarial_amd/_lib.py: ABI_VERSION) refuses a library that reports another one. */
-#define GA_ABI_VERSION 4
+#define GA_ABI_VERSION 5
 int ga_abi_version(void);
 unsigned long ga_sizeof_op(void);
 

@@ -303,6 +303,74 @@ def test_conv_halo3_fragment_weights(N, H, W, Cin, Cout, act, mode, splits, dact
     assert torch.equal(y5, y8), f'tile 8 differs from tile 5: max {float((y5 - y8).abs().max()):.3e}'
 
 
+@pytest.mark.parametrize('N,H,W,Cout,act,mode,extra', [
+    (3, 64, 64, 32, 1, 'none', 'none'),           # NVAE pre / post-processing cells: 32 -> 32 at 64 x 64, SiLU prologue
+    (2, 64, 64, 32, 1, 'affine', 'none'),         # BatchNorm affine + SiLU (conv1 of an encoder cell)
+    (5, 8, 16, 32, 0, 'per_row', 'dact'),         # one tile per image, the SE-gate prologue and the act' epilogue of a backward conv
+    (2, 16, 48, 104, 2, 'none', 'none'),          # to_logits: ELU prologue, 104 output channels = 4 channel tiles, the last one 8 wide
+    (1, 24, 32, 8, 3, 'none', 'addend'),          # 8 output channels (an image-pitch output), ReLU, identity-skip addend
+    (70, 32, 32, 32, 4, 'none', 'dact'),          # 560 tiles over 512 workgroup slots: runs of 2 tiles and a short last run, LeakyReLU
+    (9, 32, 32, 64, 0, 'affine', 'addend'),       # two channel tiles, PReLU-free affine without activation
+])
+def test_conv_thin3_persistent_kernel(N, H, W, Cout, act, mode, extra):
+    """tile 11 (csrc/conv_thin3.hip: persistent workgroups on 8 x 16 pixel tiles, the 32-channel layer's weights resident in LDS, the
+    epilogue through a 2-D row map) does tile 7's arithmetic in tile 7's order: outputs equal bit for bit, both at the split-bf16 bar
+    against torch; shapes it does not take and a missing fragment copy are refused without writing."""
+    from gen_adversarial_amd.engine_core import WeightStore
+    Cin = 32
+    x = g(N, Cin, H, W, seed=1)
+    w = g(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
+    b = g(Cout, seed=3)
+    u = x
+    kw = dict(bias=b.to(DEV), pro_act=act)
+    if mode == 'affine':
+        sc, sh = torch.rand(Cin, generator=torch.Generator().manual_seed(4)) + 0.5, g(Cin, seed=5, scale=0.3)
+        u = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV))
+    elif mode == 'per_row':
+        sc, sh = torch.rand(N, Cin, generator=torch.Generator().manual_seed(4)) + 0.5, g(N, Cin, seed=5, scale=0.3)
+        u = x * sc.view(N, Cin, 1, 1) + sh.view(N, Cin, 1, 1)
+        kw.update(pro_scale=sc.to(DEV), pro_shift=sh.to(DEV), pro_per_row=1)
+    ref = F.conv2d(ACTS[act](u), w, b, padding=1)
+    st = WeightStore(torch.device(DEV))
+    wf = fwd_w(w)
+    hi, lo = st.split(wf)
+    kw.update(w_hi=hi, w_lo=lo)
+    if extra == 'dact':
+        dx = g(N, Cout, H, W, seed=7)
+        kw.update(dact_x=nhwc(dx), dact_act=1, lddact=Cout)
+        sg = torch.sigmoid(dx)
+        ref = ref * (sg * (1 + dx * (1 - sg)))
+    elif extra == 'addend':
+        ad = g(N, Cout, H, W, seed=8)
+        kw.update(addend=nhwc(ad), ldadd=Cout)
+        ref = ref + ad
+    xd = nhwc(x)
+    y7 = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+    y11 = torch.full((N, H, W, Cout), float('nan'), device=DEV)
+    run_conv(xd, wf, y7, 3, pad=1, tile=7 if 128 % W == 0 else 4, **kw)
+    with pytest.raises(L.GaError):
+        run_conv(xd, wf, y11, 3, pad=1, tile=11, **kw)             # no fragment copy
+    assert torch.isnan(y11).all(), 'a refused launch wrote its output'
+    run_conv(xd, wf, y11, 3, pad=1, tile=11, w_frag=st.frag_thin(wf), **kw)
+    close(nchw(y11), ref, 2e-4, 'persistent thin 3x3 kernel vs torch')
+    assert torch.equal(y7, y11), f'tile 11 differs from tile 7: max {float((y7 - y11).abs().max()):.3e}'
+
+
+def test_conv_thin3_refuses_other_shapes():
+    from gen_adversarial_amd.engine_core import WeightStore
+    st = WeightStore(torch.device(DEV))
+    for (Cin, H, W) in ((64, 16, 16), (32, 12, 16), (32, 8, 24)):
+        x = g(1, Cin, H, W, seed=1)
+        w = g(32, Cin, 3, 3, seed=2)
+        wf = fwd_w(w)
+        hi, lo = st.split(wf)
+        y = torch.full((1, H, W, 32), float('nan'), device=DEV)
+        with pytest.raises(L.GaError):
+            run_conv(nhwc(x), wf, y, 3, pad=1, tile=11, w_hi=hi, w_lo=lo, w_frag=hi)
+        assert torch.isnan(y).all()
+
+
 def test_conv_halo3_per_row_prologue():
     """the SE-gate prologue of the encoder cells' conv2^T (per-(row, channel) scale and shift) on the halo kernel"""
     N, H, Cin, Cout = 5, 8, 64, 96

@@ -27,6 +27,7 @@ store = WeightStore(dev)
 hi, lo = store.split(w)
 frag = store.frag3(w)
 frag16 = store.frag3(w, m16=True)
+frag_thin = store.frag_thin(w) if Cin == 32 else None
 dact = torch.randn(N, H, H, Cout, device=dev, generator=g)
 add = torch.randn(N, H, H, Cout, device=dev, generator=g)
 ys, ds = [], []
@@ -35,7 +36,7 @@ for t in tiles:
     d = L.ConvDesc()
     d.x, d.ldx, d.C1, d.w, d.bias, d.y, d.ldy, d.Cout = x.data_ptr(), Cin, Cin, w.data_ptr(), b.data_ptr(), y.data_ptr(), Cout, Cout
     d.N, d.Hi, d.Wi, d.Ho, d.Wo, d.KH, d.KW, d.sn, d.sd, d.pad, d.tile, d.pro_act = N, H, H, H, H, 3, 3, 1, 1, 1, t, act
-    d.w_hi, d.w_lo, d.w_frag = hi.data_ptr(), lo.data_ptr(), (frag16 if t in (9, 10) else frag).data_ptr()
+    d.w_hi, d.w_lo, d.w_frag = hi.data_ptr(), lo.data_ptr(), (frag16 if t in (9, 10) else frag_thin if t == 11 else frag).data_ptr()
     if os.environ.get('GA_AB_BWD'):     # the epilogue of a backward conv: act' of a saved activation and an identity-skip addend
         d.dact_x, d.lddact, d.dact_act, d.addend, d.ldadd = dact.data_ptr(), Cout, 1, add.data_ptr(), Cout
     L.run(d)

@@ -22,6 +22,12 @@ if len(sys.argv) > 3 and sys.argv[3] == 'retune3x3':       # new halo tile codes
     for d in eng._conv_descs():
         if d.KH == 3 and d.KW == 3 and d.sn == 1 and d.sd == 1 and d.C2 == 0:
             start.pop(conv_key(d), None)
+if len(sys.argv) > 3 and sys.argv[3] == 'retune_thin':     # tile 11 (conv_thin3) is new: time the shapes it takes again
+    from gen_adversarial_amd.engine_core import conv_key, tune_cache
+    start = dict(tune_cache())
+    for d in eng._conv_descs():
+        if id(d) in eng._thin_ok:
+            start.pop(conv_key(d), None)
 cache = eng.autotune(cache=start, reps=5, save=out, verbose=True)     # default: add missing shapes
 f1, fc1, _ = eng.fwd.time(s, iters=3, per_conv=True); b1, bc1, _ = eng.bwd.time(s, iters=3, per_conv=True)
 print(f'after : fwd {f1:.2f} (conv {fc1:.2f})  bwd {b1:.2f} (conv {bc1:.2f})  entries {len(cache)}')
