@@ -943,7 +943,7 @@ def main():
                        'images_per_s': args.images * world * args.steps / dt,
                        'parallelism': f'image-sharded x{world}'},
             'roofline': {'bound': 'mfma',
-                         'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
+                         'kernel': 'ga::conv_bf3_kernel + ga::conv_halo3_kernel + ga::conv_thin3_kernel + ga::conv_mfma_kernel (implicit-GEMM conv, all instantiations)',
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': pmc_bytes,
                          'measured_peak': dict(mp, bf16x3_ceiling_tflops=meas_ceiling),
                          'frac_of_measured_peak': (achieved / meas_ceiling) if meas_ceiling else None,

@@ -25,7 +25,7 @@ env = dict(os.environ, TMPDIR='/tmp')
 
 
 def family(n):
-    return ('ga::conv_bf3_kernel' if 'conv_bf3_kernel' in n else 'ga::conv_halo3_kernel' if 'conv_halo3' in n else
+    return ('ga::conv_bf3_kernel' if 'conv_bf3_kernel' in n else 'ga::conv_halo3_kernel' if 'conv_halo3' in n else 'ga::conv_thin3_kernel' if 'conv_thin3' in n else
             'ga::conv_mfma_kernel' if 'conv_mfma_kernel' in n else 'ga::conv_splitk_reduce_kernel' if 'splitk' in n else
             'ga::dec_cell_* (fused decoder cell)' if 'dec_cell' in n else 'ga::dwconv5_kernel' if 'dwconv5' in n else 'ga::se_* (excite / apply)' if 'ga::se_' in n else
             n.split('(')[0].replace('void ', '')[:60])
@@ -70,12 +70,12 @@ for name, extra in (('1stream', ['--streams', '1']), ('2streams', [])):
     for k, (c, t) in sorted(grp.items(), key=lambda kv: -kv[1][1])[:16]:
         md.append(f'| `{k}` | {c} | {t / 1e6:.1f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} |')
     conv = sum(v[1] for k, v in grp.items() if k.startswith('ga::conv_'))
-    nconv = sum(v[0] for k, v in grp.items() if k in ('ga::conv_bf3_kernel', 'ga::conv_halo3_kernel', 'ga::conv_mfma_kernel'))
+    nconv = sum(v[0] for k, v in grp.items() if k in ('ga::conv_bf3_kernel', 'ga::conv_halo3_kernel', 'ga::conv_thin3_kernel', 'ga::conv_mfma_kernel'))
     md.append(f'\nconv launches (bf3 + halo3 + mfma; split-K reduce time included): {nconv} launches, {conv / max(nconv, 1) / 1e3:.1f} us average\n')
     shutil.rmtree(d, ignore_errors=True)                       # the raw trace is tens of MB: keep the stats only
 
 # ---- 2 + 3. PMC passes over one chunk replay
-child = BENCH + ['--pmc-child', '--chunk-rows', '512', '--eot', '32']
+child = BENCH + ['--pmc-child', '--chunk-rows', '1024', '--eot', '32']
 summary = {}
 for passname, counters in (('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE']),
                            ('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE'])):
@@ -95,7 +95,7 @@ for passname, counters in (('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES
     summary[passname] = {fam: dict(v, launches=len(launches[fam])) for fam, v in acc.items()}
     summary[passname]['_rc'] = rc
     shutil.rmtree(d, ignore_errors=True)
-res = {'_how': 'rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --pmc-child --chunk-rows 512 --eot 32 (one forward + backward replay of a '
+res = {'_how': 'rocprofv3 --pmc <counters> --kernel-trace -- python3 bench.py --pmc-child --chunk-rows 1024 --eot 32 (one forward + backward replay of a '
                '512-row chunk plan, weight preparation kernels included under "other"); counters summed over the launches of each kernel family. '
                'mfma_pipe_utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs).  FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 '
                'FETCH_SIZE counts half of the bytes of wide coalesced reads: hbm_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / launches.'}
@@ -117,7 +117,7 @@ for fam in set(summary.get('fetch', {})) | set(summary.get('write', {})):
     n = max(f_.get('launches', 0), w_.get('launches', 0), 1)
     traffic[fam] = {'launches': n, 'FETCH_SIZE_KB': f_.get('FETCH_SIZE', 0.0), 'WRITE_SIZE_KB': w_.get('WRITE_SIZE', 0.0),
                     'hbm_bytes_per_launch': (2 * f_.get('FETCH_SIZE', 0.0) + w_.get('WRITE_SIZE', 0.0)) * 1024.0 / n}
-conv = [v for k, v in traffic.items() if k in ('ga::conv_bf3_kernel', 'ga::conv_halo3_kernel', 'ga::conv_mfma_kernel')]
+conv = [v for k, v in traffic.items() if k in ('ga::conv_bf3_kernel', 'ga::conv_halo3_kernel', 'ga::conv_thin3_kernel', 'ga::conv_mfma_kernel')]
 if conv:
     traffic['conv_kernels'] = {'launches': sum(v['launches'] for v in conv),
                                'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in conv) / sum(v['launches'] for v in conv)}
