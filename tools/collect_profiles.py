@@ -71,11 +71,12 @@ for name, extra in (('1stream', ['--streams', '1']), ('2streams', [])):
         md.append(f'| `{k}` | {c} | {t / 1e6:.1f} | {t / c / 1e3:.1f} | {100 * t / tot:.1f} |')
     conv = sum(v[1] for k, v in grp.items() if k.startswith('ga::conv_'))
     nconv = sum(v[0] for k, v in grp.items() if k in ('ga::conv_bf3_kernel', 'ga::conv_halo3_kernel', 'ga::conv_thin3_kernel', 'ga::conv_mfma_kernel'))
-    md.append(f'\nconv launches (bf3 + halo3 + mfma; split-K reduce time included): {nconv} launches, {conv / max(nconv, 1) / 1e3:.1f} us average\n')
+    md.append(f'\nconv launches (bf3 + halo3 + thin3 + mfma; split-K reduce time included): {nconv} launches, {conv / max(nconv, 1) / 1e3:.1f} us average\n')
     shutil.rmtree(d, ignore_errors=True)                       # the raw trace is tens of MB: keep the stats only
 
 # ---- 2 + 3. PMC passes over one chunk replay
-child = BENCH + ['--pmc-child', '--chunk-rows', '1024', '--eot', '32']
+CHUNK_ROWS = 1024                                 # bench.py's default chunk
+child = BENCH + ['--pmc-child', '--chunk-rows', str(CHUNK_ROWS), '--eot', '32']
 summary = {}
 for passname, counters in (('mfma', ['SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE']),
                            ('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE'])):
@@ -123,8 +124,8 @@ if conv:
                                'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['launches'] for v in conv) / sum(v['launches'] for v in conv)}
 traffic['all_kernels_total_bytes'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for k, v in traffic.items() if k.startswith('ga::') or k == 'other')
 traffic['hot_path_kernels_total_bytes'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for k, v in traffic.items() if k.startswith('ga::'))
-traffic['rows'] = 512
-traffic['hbm_bytes_per_attack_row'] = traffic['hot_path_kernels_total_bytes'] / 512.0
+traffic['rows'] = CHUNK_ROWS
+traffic['hbm_bytes_per_attack_row'] = traffic['hot_path_kernels_total_bytes'] / CHUNK_ROWS.0
 traffic['_note'] = ("'other' = PyTorch kernels of engine construction (zero-filling the activation buffers, weight upload / bf16 split): not on the "
                     "hot path; hbm_bytes_per_attack_row counts the ga:: kernels only")
 res['traffic'] = traffic
