@@ -4,6 +4,15 @@
 
 namespace ga {
 
+// optional second output of the reduce pass: scaled = a * gate[n,c] (+ skip) with ga_se_apply's rounding (one fma per element)
+__device__ __forceinline__ void reduce_scaled_store(const ga_rowchan_reduce_desc& d, const floatx4 gt, const size_t o, const floatx4 a) {
+    floatx4 sk = {0.f, 0.f, 0.f, 0.f}, r;
+    if (d.skip) sk = *reinterpret_cast<const floatx4*>(d.skip + o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(gt[e], a[e], sk[e]);
+    *reinterpret_cast<floatx4*>(d.scaled + o) = r;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // out[n,c] = scale * sum_p a[n,p,c] * (b ? b[n,p,c] : 1)
 // SE squeeze = torch.mean(x, dim=[2,3]) (NVAE/modules/architecture.py:56) and its backward partner d(gate).
@@ -18,11 +27,22 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
     if (c < d.C) {
         const float* a = d.a + (size_t)n * d.P * d.C + c;
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
+        if (d.scaled) {
+            const floatx4 gt = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
+#pragma unroll 4
+            for (int p = pl; p < d.P; p += 16) {
+                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                reduce_scaled_store(d, gt, ((size_t)n * d.P + p) * d.C + c, v);
+                if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+                acc += v;
+            }
+        } else {
 #pragma unroll 8
-        for (int p = pl; p < d.P; p += 16) {
-            floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
-            if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
-            acc += v;
+            for (int p = pl; p < d.P; p += 16) {
+                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+                acc += v;
+            }
         }
     }
     part[pl][c4] = acc;
@@ -50,11 +70,22 @@ __global__ void __launch_bounds__(256) rowchan_reduce_split_kernel(const ga_rowc
         const float* a = d.a + (size_t)n * d.P * d.C + c;
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
         const int p1 = min(d.P, (seg + 1) * seg_len);
+        if (d.scaled) {
+            const floatx4 gt = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
+#pragma unroll 4
+            for (int p = seg * seg_len + pl; p < p1; p += PL) {
+                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                reduce_scaled_store(d, gt, ((size_t)n * d.P + p) * d.C + c, v);
+                if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+                acc += v;
+            }
+        } else {
 #pragma unroll 8
-        for (int p = seg * seg_len + pl; p < p1; p += PL) {
-            floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
-            if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
-            acc += v;
+            for (int p = seg * seg_len + pl; p < p1; p += PL) {
+                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
+                acc += v;
+            }
         }
     }
     part[tid] = acc;
@@ -613,6 +644,13 @@ __global__ void __launch_bounds__(256) unary_kernel(const ga_unary_desc d) {
     }
 }
 
+// address of t[n, p, c] for the StyledConv tail: interleaved [N,P,C] or the depth-to-space planes of the up-sampling layer's conv
+__device__ __forceinline__ const float* modout_t_ptr(const ga_modout_desc& d, const long n, const int p, const int c) {
+    if (!d.t_planes[0]) return d.t + ((size_t)n * d.P + p) * d.C + c;
+    const int h = p / d.W, w = p - h * d.W, H2 = (d.P / d.W) >> 1, W2 = d.W >> 1;
+    return d.t_planes[(h & 1) * 2 + (w & 1)] + (((size_t)n * H2 + (h >> 1)) * W2 + (w >> 1)) * (d.ld_planes > 0 ? d.ld_planes : d.C) + c;
+}
+
 __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, const long total4) {
     const int C4 = d.C / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
@@ -621,7 +659,7 @@ __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, con
         floatx4 sc = {1.f, 1.f, 1.f, 1.f}, ad = {0.f, 0.f, 0.f, 0.f};
         if (d.scale) sc = ld4(d.scale + n * d.C + 4 * q);
         if (d.add) ad = ld4(d.add + (size_t)p * d.C + 4 * q);
-        const floatx4 u = sc * ld4(d.t + i * 4) + ad;
+        const floatx4 u = sc * ld4(modout_t_ptr(d, n, p, 4 * q)) + ad;
         floatx4 o;
         if (!d.backward) {
 #pragma unroll
@@ -631,7 +669,7 @@ __global__ void __launch_bounds__(256) modout_kernel(const ga_modout_desc d, con
             const floatx4 g = ld4(d.dout + i * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = g[e] * act_bwd(u[e], d.act) * sc[e];
-            *reinterpret_cast<floatx4*>(d.dt + i * 4) = o;
+            if (d.dt) *reinterpret_cast<floatx4*>(d.dt + i * 4) = o;
             if (d.dt_planes[0]) {
                 const int h = p / d.W, w = p - h * d.W, H2 = (d.P / d.W) >> 1, W2 = d.W >> 1;
                 float* pl = d.dt_planes[(h & 1) * 2 + (w & 1)];
@@ -778,14 +816,14 @@ __global__ void __launch_bounds__(256) modout_bwd_reduce_kernel(const ga_modout_
         const int H2 = d.W > 0 ? (d.P / d.W) >> 1 : 0, W2 = d.W >> 1;
         for (int p = seg * seg_len + pl; p < p1; p += PL) {
             const size_t o = ((size_t)n * d.P + p) * d.C + c;
-            const floatx4 t = ld4(d.t + o);
+            const floatx4 t = ld4(modout_t_ptr(d, n, p, c));
             floatx4 u = sc * t;
             if (d.add) u += ld4(d.add + (size_t)p * d.C + c);
             const floatx4 g = ld4(d.dout + o);
             floatx4 dt;
 #pragma unroll
             for (int e = 0; e < 4; ++e) dt[e] = g[e] * act_bwd(u[e], d.act) * sc[e];
-            *reinterpret_cast<floatx4*>(d.dt + o) = dt;
+            if (d.dt) *reinterpret_cast<floatx4*>(d.dt + o) = dt;
             if (d.dt_planes[0]) {
                 const int h = p / d.W, w = p - h * d.W;
                 float* plane = d.dt_planes[(h & 1) * 2 + (w & 1)];
@@ -1170,6 +1208,7 @@ extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
     if (!d || !d->a || !d->out || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!aligned16(d->a) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
+    if (d->scaled && (!d->gate || !aligned16(d->scaled) || !aligned16(d->gate) || (d->skip && !aligned16(d->skip)))) return GA_E_BADARG;
     const int nchunks = (d->C + 63) / 64;
     if (d->ws && d->P >= 4096 && d->N * nchunks < 1024) {
         if (!aligned16(d->ws)) return GA_E_ALIGN;
@@ -1303,17 +1342,21 @@ extern "C" int ga_unary(const ga_unary_desc* d, void* s) {
 
 extern "C" int ga_modout(const ga_modout_desc* d, void* s) {
     ga::clear_stale_error();
-    if (!d || !d->t || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (!d || (!d->t && !d->t_planes[0]) || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
     if (!d->backward && !d->out) return GA_E_BADARG;
-    if (d->backward && (!d->dout || !d->dt)) return GA_E_BADARG;
-    if (d->backward && d->dt_planes[0]) {
-        if (!d->dt_planes[1] || !d->dt_planes[2] || !d->dt_planes[3]) return GA_E_BADARG;
+    if (d->backward && (!d->dout || (!d->dt && !d->dt_planes[0]))) return GA_E_BADARG;
+    if ((d->backward && d->dt_planes[0]) || d->t_planes[0]) {
+        if (d->backward && d->dt_planes[0] && (!d->dt_planes[1] || !d->dt_planes[2] || !d->dt_planes[3])) return GA_E_BADARG;
+        if (d->t_planes[0] && (!d->t_planes[1] || !d->t_planes[2] || !d->t_planes[3])) return GA_E_BADARG;
         if (d->W <= 0 || d->W % 2 || d->P % d->W || (d->P / d->W) % 2) return GA_E_BADARG;
+        if (d->ld_planes % 4) return GA_E_UNSUPPORTED;
+        for (int i = 0; i < 4; ++i)
+            if ((d->t_planes[0] && !aligned16(d->t_planes[i])) || (d->backward && d->dt_planes[0] && !aligned16(d->dt_planes[i]))) return GA_E_ALIGN;
     }
     if (d->backward && d->red) {
         if (!d->ws || d->ws_floats < (long)d->N * d->C) return GA_E_BADARG;
-        if (!aligned16(d->ws) || !aligned16(d->t) || !aligned16(d->dout) || !aligned16(d->dt)) return GA_E_ALIGN;
+        if (!aligned16(d->ws) || (d->t && !aligned16(d->t)) || !aligned16(d->dout) || (d->dt && !aligned16(d->dt))) return GA_E_ALIGN;
         const int nchunks = (d->C + 63) / 64;
         long S = d->ws_floats / ((long)d->N * d->C);
         const long want = (2048 + (long)d->N * nchunks - 1) / ((long)d->N * nchunks);     // ~8 workgroups per CU

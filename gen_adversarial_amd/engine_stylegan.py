@@ -14,11 +14,13 @@ the OUTPUT channels in the tail pass (folding.fold_styled_conv).  Forward / back
   dt     = dout * act'(u) * demod               ga_modout (u recomputed; sum_p dt t reduced in the same pass)
   d(W2 s^2) = -1/2 demod^2 sum_p dt t           ga_unary
   ds     = 2 s W2^T d(W2 s^2) + sum_p dxm x     ga_conv2d 1x1, ga_unary, ga_rowchan_reduce, ga_axpby
-  dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d, ga_se_apply (row scale, accumulating into x.g)
+  dxm    = conv^T(W, dt);  dx = dxm * s         ga_conv2d; the row scale (accumulating into x.g) rides on the ga_rowchan_reduce pass
+                                                that forms sum_p dxm x: one read of dxm for both
   dw_latent += modulation^T ds                  ga_conv2d 1x1
 Up-sampling layer: transposed conv + blur = one 6x6 / stride-2 transposed conv (folding.upsample_conv_weights) = four 3x3
-parity convs, run as ONE 3x3 conv Cin -> 4*Cout into the depth-to-space form + ga_interleave2 forward; backward one 3x3
-conv 4*Cout -> Cin over the cotangent in depth-to-space form (written by ga_modout beside the interleaved one).  ToRGB skip: ga_up2_blur.
+parity convs, run as ONE 3x3 conv Cin -> 4*Cout into the depth-to-space form, which the tail reads directly (ga_modout_desc.t_planes:
+no interleave pass, no interleaved t); backward one 3x3 conv 4*Cout -> Cin over the cotangent that ga_modout writes in the same
+depth-to-space form.  ToRGB skip: ga_up2_blur.
 """
 from __future__ import annotations
 
@@ -73,17 +75,23 @@ class StyleGanBuilder:
         self.conv(self.fwd, f'{p}.modulation', w_latent.t, wts['wm'], s.t, bias=wts['bm'], K=1, ldx=lat_ld)
         zeros = self.devd(f'sg.zeros.{R}.{spec.cin}', lambda: {'z': torch.zeros(R, spec.cin)})['z']
         pro = dict(pro_scale=s.t, pro_shift=zeros, pro_per_row=1)
-        t = Act(self, R, spec.res, spec.res, co, f'{p}.t')
-        if spec.upsample:                # all four parities as one 3x3 conv Cin -> 4*Cout over the low-resolution input
-            s2d = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d')
+        t = s2d = None
+        if spec.upsample:                # all four parities as one 3x3 conv Cin -> 4*Cout over the low-resolution input; t STAYS in
+            # that depth-to-space form [R, rin, rin, 4*Cout] (channel block i = parity plane i): the tail and its adjoint read it through
+            # ga_modout_desc.t_planes — no interleave pass, no interleaved copy of t or of its gradient (round 4)
+            s2d = self.alloc((R, rin, rin, 4 * co))
             self.conv(self.fwd, f'{p}.conv[parities]', x.t, wts['up_all'], s2d, K=3, pad=1, **pro)
-            il = L.Interleave2Desc()
-            for i in range(4):
-                il.s[i] = _ptr(s2d) + 4 * i * co                 # channel block i of the depth-to-space tensor
-            il.y, il.N, il.H, il.W, il.C, il.lds = _ptr(t.t), R, spec.res, spec.res, co, 4 * co
-            self.fwd.add(il, f'{p}.conv.interleave')
         else:
+            t = Act(self, R, spec.res, spec.res, co, f'{p}.t')
             self.conv(self.fwd, f'{p}.conv', x.t, wts['w'], t.t, K=k, pad=k // 2, **pro)
+
+        def tail_t(m):                   # where the tail finds t
+            if s2d is None:
+                m.t = _ptr(t.t)
+                return
+            m.W, m.ld_planes = spec.res, 4 * co
+            for i in range(4):
+                m.t_planes[i] = _ptr(s2d) + 4 * i * co
         demod = None
         if spec.demodulate:
             s2 = self.alloc((R, 1, 1, spec.cin))
@@ -94,8 +102,9 @@ class StyleGanBuilder:
             self._unary(self.fwd, f'{p}.demod', 2, q, None, demod, eps=1e-8)
         out = Act(self, R, spec.res, spec.res, co, f'{p}.out')
         m = L.ModoutDesc()
-        m.t, m.scale, m.add, m.out = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.t)
+        m.scale, m.add, m.out = _ptr(demod), _ptr(wts['add']), _ptr(out.t)
         m.N, m.P, m.C, m.act, m.backward = R, P, co, act, 0
+        tail_t(m)
         self.fwd.add(m, f'{p}.tail')
         if skip is not None:
             assert (skip.n, skip.h, skip.w, skip.c) == (R, spec.res // 2, spec.res // 2, co), p
@@ -111,14 +120,16 @@ class StyleGanBuilder:
                 self.bwd.add(ub, f'{p}.skip_upsample^T')
                 skip.g_written = True
             b = L.ModoutDesc()
-            b.t, b.scale, b.add, b.dout, b.dt = _ptr(t.t), _ptr(demod), _ptr(wts['add']), _ptr(out.g), _ptr(t.g)
+            b.scale, b.add, b.dout = _ptr(demod), _ptr(wts['add']), _ptr(out.g)
             b.N, b.P, b.C, b.act, b.backward = R, P, co, act, 1
+            tail_t(b)
             s2d_g = None
-            if spec.upsample:                                    # dt also in depth-to-space form: the operand of the parity adjoint
-                s2d_g = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d')
-                b.W, b.ld_planes = spec.res, 4 * co
+            if spec.upsample:                                    # dt in depth-to-space form only: the operand of the parity adjoint
+                s2d_g = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d_g')
                 for i in range(4):
                     b.dt_planes[i] = _ptr(s2d_g) + 4 * i * co
+            else:
+                b.dt = _ptr(t.g)
             gq = None
             if spec.demodulate:                                  # sum_p dt * t rides on the tail's adjoint (no second read of dt, t)
                 gq = self.scratch((R, 1, 1, co), 'sg.gq')
@@ -131,7 +142,11 @@ class StyleGanBuilder:
                 self.conv(self.bwd, f'{p}.conv^T[parities]', s2d_g, wts['up_all_bwd'], dxm, K=3, pad=1)
             else:
                 self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
-            self._reduce(f'{p}.dstyle_conv', dxm, x.t, ds, R, Pin, spec.cin)
+            # sum_p dxm * x (style gradient) and d x = dxm * s (+ an already written x.g) from ONE read of dxm (round 4)
+            self._reduce(f'{p}.dstyle_conv' + ('+dx' if need_dx else ''), dxm, x.t, ds, R, Pin, spec.cin,
+                         scaled=(x.g if need_dx else None), gate=s.t, skip=(x.g if need_dx and x.g_written else None))
+            if need_dx:
+                x.g_written = True
             if spec.demodulate:
                 ds2 = self.scratch((R, 1, 1, spec.cin), 'sg.ds2')
                 self._unary(self.bwd, f'{p}.demod^T', 3, demod, gq, gq)
@@ -143,13 +158,6 @@ class StyleGanBuilder:
             self.conv(self.bwd, f'{p}.modulation^T', ds, wts['wm_bwd'], w_latent.g, K=1, ldy=lat_ld,
                       addend=(w_latent.g if w_latent.g_written else None), ldadd=lat_ld)
             w_latent.g_written = True
-            if need_dx:
-                ap = L.SeApplyDesc()                             # dx = dxm * s (+ an already written x.g)
-                ap.skip = _ptr(x.g) if x.g_written else None
-                ap.t, ap.gate, ap.out = _ptr(dxm), _ptr(s.t), _ptr(x.g)
-                ap.N, ap.H, ap.W, ap.C, ap.skip_mode, ap.res_scale = R, rin, rin, spec.cin, 0, 1.0
-                self.bwd.add(ap, f'{p}.dx')
-                x.g_written = True
         self._bwd_steps.append(backward)
         return out
 
@@ -268,9 +276,11 @@ class StyleGanBuilder:
         u.x, u.g, u.y, u.n, u.mode, u.eps = _ptr(x), _ptr(g), _ptr(y), y.numel(), mode, eps
         plan.add(u, name)
 
-    def _reduce(self, name, a, b, out, n, p, c):
+    def _reduce(self, name, a, b, out, n, p, c, scaled=None, gate=None, skip=None):
         r = L.ReduceDesc()
         r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(a), _ptr(b), _ptr(out), n, p, c, 1.0
+        if scaled is not None:
+            r.scaled, r.gate, r.skip = _ptr(scaled), _ptr(gate), _ptr(skip)
         if p >= 4096:                                    # long rows: split the pixels over workgroups (two-stage reduction)
             ws = self.scratch((256 * n * c,), 'sg.reduce_ws')
             r.ws, r.ws_floats = _ptr(ws), ws.numel()

@@ -143,6 +143,10 @@ typedef struct ga_rowchan_reduce_desc {
     const float* a; const float* b; float* out;
     int N, P, C; float scale;
     float* ws; long ws_floats;
+    /* optional second output of the same pass (round 4; StyledConv backward, generator.py:166-203 differentiated):
+     *   scaled[n,p,c] = a[n,p,c] * gate[n,c] (+ skip[n,p,c])     — d x = d(x*s) * s beside the style gradient sum_p d(x*s) * x,
+     * one read of `a` for both.  skip may alias scaled (accumulating into an already written gradient). */
+    const float* gate; const float* skip; float* scaled;
 } ga_rowchan_reduce_desc;
 int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* stream);
 
@@ -293,6 +297,10 @@ typedef struct ga_modout_desc {
     float* red;               /* backward, optional: red[n, c] = sum_p dt[n,p,c] * t[n,p,c] (the demodulation gradient's reduction,
                                  fused into this pass; deterministic two-stage sum through ws, ws_floats >= N*C) */
     float* ws; long ws_floats;
+    const float* t_planes[4]; /* optional (round 4): t is READ in the depth-to-space form the up-sampling layer's parity conv writes
+                                 (pixel (h, w) at plane (h&1)*2 + (w&1), [n, h/2, w/2, ld_planes]) instead of from `t` (then NULL):
+                                 no interleave pass between the conv and its tail.  With t_planes AND dt_planes given, `dt` may be
+                                 NULL (the parity adjoint reads the planes only). */
 } ga_modout_desc;
 int ga_modout(const ga_modout_desc* d, void* stream);
 
@@ -596,7 +604,7 @@ long ga_debug_set_conv_row_limit(long bytes);
 const char* ga_last_hip_error(void);
 /* GA_ABI_VERSION is bumped with EVERY change of a descriptor's layout or meaning (a field added, a reserved field put to use) and
  * with every entry point added; the binding (gen_adversarial_amd/_lib.py: ABI_VERSION) refuses a library that reports another one. */
-#define GA_ABI_VERSION 5
+#define GA_ABI_VERSION 6
 int ga_abi_version(void);
 unsigned long ga_sizeof_op(void);
 

@@ -288,7 +288,9 @@ def test_stylegan_generator_plans_build_without_a_gpu():
     eng.finish()
     assert (img.h, img.w, img.c) == (32, 32, 4)
     names = eng.bwd.names
-    assert 'conv1.dx' not in names and 'convs.0.dx' in names
+    # d x rides on the style-gradient reduction of its layer (one read of the conv^T output); the constant input gets none
+    assert 'conv1.dstyle_conv' in names and 'convs.0.dstyle_conv+dx' in names and not any(n.endswith('.dx') for n in names)
+    assert not any(n.endswith('interleave') for n in eng.fwd.names)      # t stays in the parity conv's depth-to-space form
     mods = {n: d for d, n in zip(eng.bwd.descs, names) if n.endswith('modulation^T')}
     assert len(mods) == 11
     assert not mods['to_rgbs.2.modulation^T'].addend            # latent[:, 7]: one reader

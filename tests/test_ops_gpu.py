@@ -1073,6 +1073,98 @@ def test_rowchan_reduce_two_stage(N, P, C, with_b):
     assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('N,P,C,two_stage,with_skip', [(3, 5000, 32, True, True), (2, 16384, 4, True, False), (2, 300, 96, False, True),
+                                                       (1, 70000, 64, True, True), (4, 64, 512, False, False)])
+def test_rowchan_reduce_with_scaled_output(N, P, C, two_stage, with_skip):
+    """StyledConv backward (generator.py:166-203 differentiated): sum_p a * b and scaled = a * gate[n,c] (+ skip, in place) from one
+    pass; the sum equals the plain reduction bit for bit, the scaled output equals ga_se_apply's"""
+    gen = torch.Generator().manual_seed(N * 1000 + C)
+    a, b = torch.randn(N, P, C, generator=gen).to(DEV), torch.randn(N, P, C, generator=gen).to(DEV)
+    gate = torch.randn(N, C, generator=gen).to(DEV)
+    acc0 = torch.randn(N, P, C, generator=gen).to(DEV)
+    out, out_ref = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV)
+    ws = torch.zeros(64 * N * C, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    d = L.ReduceDesc()
+    d.a, d.b, d.out, d.N, d.P, d.C, d.scale = a.data_ptr(), b.data_ptr(), out_ref.data_ptr(), N, P, C, 1.0
+    if two_stage:
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    L.run(d, st)
+    scaled = acc0.clone() if with_skip else torch.full((N, P, C), float('nan'), device=DEV)
+    d.out, d.gate, d.scaled = out.data_ptr(), gate.data_ptr(), scaled.data_ptr()
+    d.skip = scaled.data_ptr() if with_skip else None
+    L.run(d, st)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out_ref)
+    ap = L.SeApplyDesc()
+    ref = acc0.clone() if with_skip else torch.zeros(N, P, C, device=DEV)
+    ap.skip = ref.data_ptr() if with_skip else None
+    ap.t, ap.gate, ap.out = a.data_ptr(), gate.data_ptr(), ref.data_ptr()
+    ap.N, ap.H, ap.W, ap.C, ap.skip_mode, ap.res_scale = N, 1, P, C, 0, 1.0
+    L.run(ap, st)
+    torch.cuda.synchronize()
+    assert torch.equal(scaled, ref)
+    want = a.double() * gate.double()[:, None, :] + (acc0.double() if with_skip else 0.0)
+    assert (scaled.double() - want).abs().max().item() < 1e-5
+    d.gate = None                                             # a scaled output without its gate is refused
+    import ctypes
+    assert L.lib.ga_rowchan_reduce(ctypes.byref(d), st) == -1           # GA_E_BADARG
+
+
+@pytest.mark.parametrize('N,H,C,with_red,act', [(2, 16, 32, True, L.GA_ACT_FLRELU), (3, 8, 8, False, L.GA_ACT_FLRELU), (1, 64, 64, True, L.GA_ACT_NONE)])
+def test_modout_reads_t_in_depth_to_space_form(N, H, C, with_red, act):
+    """the up-sampling StyledConv keeps t in the parity conv's depth-to-space form: tail forward, its adjoint (dt in planes only) and the
+    fused demodulation reduction equal the interleaved path bit for bit"""
+    gen = torch.Generator().manual_seed(H * 100 + C)
+    P, h2 = H * H, H // 2
+    s2d = torch.randn(N, h2, h2, 4 * C, generator=gen).to(DEV)
+    t = s2d.view(N, h2, h2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H, H, C).contiguous()     # pixel (2y+a, 2x+b) <- plane 2a+b
+    scale = (1.0 + 0.2 * torch.randn(N, C, generator=gen)).to(DEV)
+    add = torch.randn(P, C, generator=gen).to(DEV)
+    dout = torch.randn(N, P, C, generator=gen).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def desc(backward, planes):
+        m = L.ModoutDesc()
+        m.scale, m.add, m.N, m.P, m.C, m.act, m.backward = scale.data_ptr(), add.data_ptr(), N, P, C, act, backward
+        if planes:
+            m.W, m.ld_planes = H, 4 * C
+            for i in range(4):
+                m.t_planes[i] = s2d.data_ptr() + 4 * i * C
+        else:
+            m.t = t.data_ptr()
+        return m
+    o_ref, o = torch.zeros(N, P, C, device=DEV), torch.zeros(N, P, C, device=DEV)
+    m = desc(0, False); m.out = o_ref.data_ptr(); L.run(m, st)
+    m = desc(0, True); m.out = o.data_ptr(); L.run(m, st)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o_ref)
+    u = scale[:, None, :] * t.view(N, P, C) + add[None]
+    want = torch.nn.functional.leaky_relu(u, 0.2) * 2 ** 0.5 if act == L.GA_ACT_FLRELU else u
+    assert (o - want).abs().max().item() < 1e-5
+    # backward: interleaved dt + planes (old form) against planes only, t from planes
+    dt_ref, pl_ref, pl = torch.zeros(N, P, C, device=DEV), torch.zeros(N, h2, h2, 4 * C, device=DEV), torch.zeros(N, h2, h2, 4 * C, device=DEV)
+    red_ref, red = torch.zeros(N, C, device=DEV), torch.zeros(N, C, device=DEV)
+    ws = torch.zeros(256 * N * C, device=DEV)
+    for planes, dt, plb, rd in ((False, dt_ref, pl_ref, red_ref), (True, None, pl, red)):
+        b = desc(1, planes)
+        b.dout = dout.data_ptr()
+        b.dt = dt.data_ptr() if dt is not None else None
+        b.W, b.ld_planes = H, 4 * C
+        for i in range(4):
+            b.dt_planes[i] = plb.data_ptr() + 4 * i * C
+        if with_red:
+            b.red, b.ws, b.ws_floats = rd.data_ptr(), ws.data_ptr(), ws.numel()
+        L.run(b, st)
+    torch.cuda.synchronize()
+    assert torch.equal(pl, pl_ref) and torch.equal(red, red_ref)
+    assert torch.equal(pl.view(N, h2, h2, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, P, C), dt_ref)
+    b = desc(1, True)                                         # neither dt nor planes: refused
+    b.dout = dout.data_ptr()
+    import ctypes
+    assert L.lib.ga_modout(ctypes.byref(b), st) == -1                   # GA_E_BADARG
+
+
 def test_conv_beyond_2gb_runs_in_row_sub_batches():
     """an input past the fast loader's 31-bit byte offsets (StyleGAN2's 1024^2 maps at a few dozen rows) is convolved in
     sub-batches of rows: same numbers as one launch per row"""
