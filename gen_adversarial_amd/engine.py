@@ -285,7 +285,12 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             self.small_kinks = []
         self.small_kinks.append(hid)                        # pre-ReLU hidden units, in call order (parity tests replay their decisions)
         e = L.SeExciteDesc()
-        e.t = _ptr(t.t)                                     # fused squeeze + excite (one workgroup per row)
+        if merge is None and self._se_wide_rows(n, P, c):   # few rows of large images: squeeze over the whole chip first
+            m = self.alloc((n, c))
+            self._se_reduce(self.fwd, f'{name}.se_squeeze', t.t, None, m, n, P, c, 1.0 / P)
+            e.m = _ptr(m)
+        else:
+            e.t = _ptr(t.t)                                 # fused squeeze + excite (one workgroup per row)
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
         e.hid, e.gate, e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = (_ptr(hid), _ptr(gate), n, c, hd, P,
                                                                         RES_SCALE if res_scale is None else res_scale, 0)
@@ -293,6 +298,21 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
             e.skip, e.out = _ptr(merge[0]), _ptr(merge[1])
         self.fwd.add(e, f'{name}.se_gate' + ('+merge' if merge is not None else ''))
         return gate, hid
+
+    @staticmethod
+    def _se_wide_rows(n, P, c) -> bool:
+        """the fused squeeze of ga_se_excite is one workgroup per row: right for hundreds of small rows (the NVAE cells), 32 workgroups
+        for the chip on the IR-SE50 body of the e4e / Style-Transformer defenders (32 - 64 rows of 128^2 x 64 ... 32^2 x 256: 1 - 4 MB per
+        row, 190 us per backward launch).  Those rows are reduced by ga_rowchan_reduce (one workgroup per row and 64 channels; from 4096
+        pixels its two-stage form, pixels split over workgroups) and the excite kernel takes the reduced vector (its `m` / `dgate` inputs)."""
+        return n <= 128 and P >= 1024 and P * c >= 262144 and c % 4 == 0
+
+    def _se_reduce(self, plan, name, a, b, out, n, P, c, scale):
+        r = L.ReduceDesc()
+        r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(a), _ptr(b), _ptr(out), n, P, c, scale
+        ws = self.scratch((256 * n * c,), 'se_reduce_ws')
+        r.ws, r.ws_floats = _ptr(ws), ws.numel()
+        plan.add(r, name)
 
     def se_merges(self, t: Act, P) -> bool:
         return P * t.c <= self.SE_FUSED_MERGE_MAX and t.c % 4 == 0
@@ -303,8 +323,14 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
         ps = self.scratch((n, c), f'ps{c}')
         pb = self.scratch((n, c), f'pb{c}')
         e = L.SeExciteDesc()
-        e.act_rep = self.cot_rep
-        e.t, e.dout = _ptr(t.t), _ptr(dout)                 # fused d(gate) reduction + excite backward
+        rs = RES_SCALE if res_scale is None else res_scale
+        if self.cot_rep == 1 and self._se_wide_rows(n, P, c):
+            dg = self.scratch((n, c), f'se_dgate{c}')       # d(gate) = res_scale * sum_p dout * t, reduced over the whole chip
+            self._se_reduce(self.bwd, f'{name}.se_dgate', t.t, dout, dg, n, P, c, rs)
+            e.dgate = _ptr(dg)
+        else:
+            e.act_rep = self.cot_rep
+            e.t, e.dout = _ptr(t.t), _ptr(dout)             # fused d(gate) reduction + excite backward
         e.w1, e.b1, e.w2, e.b2 = _ptr(wts['se_w1']), _ptr(wts['se_b1']), _ptr(wts['se_w2']), _ptr(wts['se_b2'])
         e.hid, e.gate, e.pro_scale, e.pro_shift = _ptr(hid), _ptr(gate), _ptr(ps), _ptr(pb)
         e.N, e.C, e.Hd, e.P, e.res_scale, e.backward = n, c, wts['se_w1'].shape[0], P, (RES_SCALE if res_scale is None else res_scale), 1

@@ -70,6 +70,16 @@ for plan, tag in ((eng.fwd, 'fwd'), (eng.bwd, 'bwd')):
         print(f'   generator {k:28s} n {n:3d} {t:9.3f} ms')
     top = sorted(zip(ms, plan.names), reverse=True)[:12]
     print('   top ops: ' + ', '.join(f'{n} {t:.2f}' for t, n in top))
+    enc = collections.OrderedDict()                              # the encoder by op kind and shape
+    for d, nm, t in zip(plan.descs, plan.names, ms):
+        if section(nm) != 'encoder':
+            continue
+        k = type(d).__name__
+        if isinstance(d, L.ConvDesc):
+            k += f' K{d.KH}s{d.sn}d{d.sd} {d.N * d.Ho * d.Wo}x{d.C1 + d.C2}->{d.Cout}'
+        e = enc.setdefault(k, [0, 0.0]); e[0] += 1; e[1] += t
+    for k, (n, t) in sorted(enc.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f'   encoder {k:44s} n {n:3d} {t:9.3f} ms')
 
 if os.environ.get('GA_GRAPHS', '0') == '1':                 # eager plan replay vs HIP graphs, wall clock per attack step
     def wall(n):
