@@ -567,6 +567,7 @@ extern "C" int ga_dec_cell_halo(const ga_dec_cell_halo_desc* d, void* s) {
     }
     if (!d->wd_bwd || !d->w1t_hi || !d->w1t_lo || !d->dout || !d->pro_scale || !d->pro_shift) return GA_E_BADARG;
     if (!ga::aligned16(d->dout) || !ga::aligned16(d->pro_scale) || !ga::aligned16(d->pro_shift) || !ga::aligned16(d->wd_bwd) ||
-        !ga::aligned16(d->w1t_hi) || !ga::aligned16(d->w1t_lo)) return GA_E_ALIGN;
+        !ga::aligned16(d->w1t_hi) || !ga::aligned16(d->w1t_lo) || (d->addend && !ga::aligned16(d->addend)) ||
+        (d->addend2 && !ga::aligned16(d->addend2))) return GA_E_ALIGN;
     return d->Cin == 32 ? ga::launch_hc_bwd<32>(*d, gm, stream) : ga::launch_hc_bwd<64>(*d, gm, stream);
 }

@@ -414,7 +414,9 @@ int ga_dec_cell_supported(int N, int H, int W, int C, int Hd);   /* 1 when ga_de
  * owns an 8 x 16 pixel tile and recomputes the expand conv on the tile's halo; csrc/dec_cell_halo.hip.
  *   forward  (backward = 0): y = t3 [N,H,W,C] as ga_dec_cell
  *   backward (backward = 1): y = dx [N,H,W,C] = addend + addend2 + W1^T . dt1, dt1 as ga_dec_cell's backward (never stored);
- *            w2 = W2^T [Hd][C] as there, w1t = W1^T [C][Hd] (the backward weight of the expand conv), addends optional.
+ *            w2 = W2^T [Hd][C] as there, w1t = W1^T [C][Hd] (the backward weight of the expand conv), addends optional;
+ *            each addend is [N,H,W,C], 16-byte aligned, and MAY ALIAS y (every element is read and written by the same thread:
+ *            in-place accumulation into an already written gradient).
  * Cin == Cout in {32, 64}, Hd % 32 == 0, H % 8 == 0, W % 16 == 0 (ga_dec_cell_halo_supported); up must be 0. */
 typedef struct ga_dec_cell_halo_desc {
     const float* x;
