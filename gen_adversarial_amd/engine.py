@@ -178,8 +178,8 @@ class Engine(NvaeBuilder, NdvaeBuilder, AvaeBuilder, ClassifierBuilder, E4EBuild
                 # LAZILY — by apply_tuning for the descs whose tuned tile is 8, by autotune for its candidates — not for every
                 # eligible 3x3 weight (52 of 1594 tuned shapes select tile 8; an eager copy doubled the split-weight memory)
                 self._frag_ok[id(d)] = w
-            if (kh, kw, sn, sd, pad) == (3, 3, 1, 1, 1) and x2 is None and (cin or x.shape[3]) == 32 and x.shape[1] % 8 == 0 \
-                    and x.shape[2] % 16 == 0 and w.dim() == 2 and w.shape[1] == 9 * 32:
+            if (kh, kw, sn, sd, pad) == (3, 3, 1, 1, 1) and x2 is None and (cin or x.shape[3]) in (32, 64) and x.shape[1] % 8 == 0 \
+                    and x.shape[2] % 16 == 0 and w.dim() == 2 and w.shape[1] == 9 * (cin or x.shape[3]):
                 self._thin_ok[id(d)] = w                    # tile 11 (conv_thin3): persistent weights-resident kernel, its own fragment order
         d.pro_scale, d.pro_shift, d.pro_act, d.pro_per_row = _ptr(pro_scale), _ptr(pro_shift), pro_act, pro_per_row
         No, Ho, Wo, Cy = y.shape

@@ -81,20 +81,20 @@ class WeightStore:
         return self.splits[k][0]
 
     def frag_thin(self, w: torch.Tensor) -> torch.Tensor:
-        """the split weights of a 3x3 conv with 32 input channels ([Cout][9 * 32] fp32) in the order of tile 11 (conv_thin3.hip):
-        bf16 [ceil(Cout/32)][9 taps][2 k steps][hi | lo][64 lanes][8], lane = 32 * (k octet of the 16-deep step) + channel"""
+        """the split weights of a 3x3 conv with C = 32 or 64 input channels ([Cout][9 * C] fp32) in the order of tile 11 (conv_thin3.hip):
+        bf16 [ceil(Cout/32)][9 taps][C/16 k steps][hi | lo][64 lanes][8], lane = 32 * (k octet of the 16-deep step) + channel"""
         k = ('frag_thin', w.data_ptr())
         if k not in self.splits:
             hi, lo = self.split(w)
             cout, kk = w.shape
-            assert kk == 9 * 32, tuple(w.shape)
-            nt = (cout + 31) // 32
+            assert kk in (9 * 32, 9 * 64), tuple(w.shape)
+            nt, ks = (cout + 31) // 32, kk // 9 // 16
 
             def arr(t):
                 tp = torch.zeros(nt * 32, kk, dtype=torch.bfloat16, device=t.device)
                 tp[:cout] = t
                 # [nt, channel, tap, k step, k octet, e] -> [nt, tap, k step, k octet, channel, e]
-                return tp.view(nt, 32, 9, 2, 2, 8).permute(0, 2, 3, 4, 1, 5)
+                return tp.view(nt, 32, 9, ks, 2, 8).permute(0, 2, 3, 4, 1, 5)
             f = torch.stack([arr(hi), arr(lo)], dim=3).contiguous()            # hi | lo between the k step and the lane
             self.splits[k] = (f, w)
             self.bytes += 2 * f.numel()

@@ -86,7 +86,7 @@ typedef struct ga_conv_desc {
                                               pad 1, C1 % 32 == 0, 128 % Wo == 0 or Wo % 128 == 0, w_hi/w_lo given;
                                               GA_E_UNSUPPORTED otherwise); 8 = 128x128 on the same kernel with the weight
                                               fragments read from global memory (w_frag given, 128 % Wo == 0);
-                                              11 = persistent weights-resident 3x3 for C1 == 32 on 8 x 16 pixel tiles (3x3, stride 1,
+                                              11 = persistent weights-resident 3x3 for C1 == 32 or 64 on 8 x 16 pixel tiles (3x3, stride 1,
                                               pad 1, Ho % 8 == 0, Wo % 16 == 0, no split-K, w_frag given in the tile-11 order below) */
     int splits;                            /* split-K factor (<=1: none); needs ws */
     float* ws;                             /* split-K workspace, >= splits*N*Ho*Wo*Cout floats, or NULL */
@@ -105,10 +105,10 @@ typedef struct ga_conv_desc {
                                               lane l = W[128 t + 32 wave + (l & 31)][tap * C1 + 32 chunk + 16 kstep + 8 (l >> 5) + e]
                                               (rows >= Cout zero).  The halo kernel then reads its B fragments from global memory:
                                               no weight staging through LDS, one barrier per 32-channel chunk.
-                                              Tile 11 (C1 == 32) takes another order of the same weights:
-                                              [ceil(Cout/32)][9 taps][2 k steps][hi | lo][64 lanes][8], element e of lane l =
-                                              W[32 t + (l & 31)][tap * 32 + 16 kstep + 8 (l >> 5) + e] (rows >= Cout zero): each workgroup
-                                              keeps one 36-KB block in LDS for its lifetime */
+                                              Tile 11 (C1 == 32 or 64) takes another order of the same weights:
+                                              [ceil(Cout/32)][9 taps][C1/16 k steps][hi | lo][64 lanes][8], element e of lane l =
+                                              W[32 t + (l & 31)][tap * C1 + 16 kstep + 8 (l >> 5) + e] (rows >= Cout zero): each workgroup
+                                              keeps one 36-KB (C1 == 64: 72-KB) block in LDS for its lifetime */
 } ga_conv_desc;
 int ga_conv2d(const ga_conv_desc* d, void* stream);
 

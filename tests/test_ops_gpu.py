@@ -303,21 +303,24 @@ def test_conv_halo3_fragment_weights(N, H, W, Cin, Cout, act, mode, splits, dact
     assert torch.equal(y5, y8), f'tile 8 differs from tile 5: max {float((y5 - y8).abs().max()):.3e}'
 
 
-@pytest.mark.parametrize('N,H,W,Cout,act,mode,extra', [
-    (3, 64, 64, 32, 1, 'none', 'none'),           # NVAE pre / post-processing cells: 32 -> 32 at 64 x 64, SiLU prologue
-    (2, 64, 64, 32, 1, 'affine', 'none'),         # BatchNorm affine + SiLU (conv1 of an encoder cell)
-    (5, 8, 16, 32, 0, 'per_row', 'dact'),         # one tile per image, the SE-gate prologue and the act' epilogue of a backward conv
-    (2, 16, 48, 104, 2, 'none', 'none'),          # to_logits: ELU prologue, 104 output channels = 4 channel tiles, the last one 8 wide
-    (1, 24, 32, 8, 3, 'none', 'addend'),          # 8 output channels (an image-pitch output), ReLU, identity-skip addend
-    (70, 32, 32, 32, 4, 'none', 'dact'),          # 560 tiles over 512 workgroup slots: runs of 2 tiles and a short last run, LeakyReLU
-    (9, 32, 32, 64, 0, 'affine', 'addend'),       # two channel tiles, PReLU-free affine without activation
+@pytest.mark.parametrize('N,H,W,Cout,act,mode,extra,Cin', [
+    (3, 64, 64, 32, 1, 'none', 'none', 32),       # NVAE pre / post-processing cells: 32 -> 32 at 64 x 64, SiLU prologue
+    (2, 64, 64, 32, 1, 'affine', 'none', 32),     # BatchNorm affine + SiLU (conv1 of an encoder cell)
+    (5, 8, 16, 32, 0, 'per_row', 'dact', 32),     # one tile per image, the SE-gate prologue and the act' epilogue of a backward conv
+    (2, 16, 48, 104, 2, 'none', 'none', 32),      # to_logits: ELU prologue, 104 output channels = 4 channel tiles, the last one 8 wide
+    (1, 24, 32, 8, 3, 'none', 'addend', 32),      # 8 output channels (an image-pitch output), ReLU, identity-skip addend
+    (70, 32, 32, 32, 4, 'none', 'dact', 32),      # 560 tiles over 512 workgroup slots: runs of 2 tiles and a short last run, LeakyReLU
+    (9, 32, 32, 64, 0, 'affine', 'addend', 32),   # two channel tiles, PReLU-free affine without activation
+    (3, 32, 32, 64, 1, 'affine', 'none', 64),     # 64 input channels (one workgroup per CU): 64 -> 64 at 32 x 32, BatchNorm + SiLU
+    (5, 8, 16, 64, 0, 'per_row', 'dact', 64),     # ... the SE-gate prologue and the act' epilogue
+    (40, 32, 32, 128, 0, 'none', 'addend', 64),   # ... 4 channel tiles, 640 tiles over 64 runs of 10
+    (2, 24, 48, 32, 4, 'none', 'none', 64),       # ... LeakyReLU, rows and columns that are not powers of two
 ])
-def test_conv_thin3_persistent_kernel(N, H, W, Cout, act, mode, extra):
+def test_conv_thin3_persistent_kernel(N, H, W, Cout, act, mode, extra, Cin):
     """tile 11 (csrc/conv_thin3.hip: persistent workgroups on 8 x 16 pixel tiles, the 32-channel layer's weights resident in LDS, the
     epilogue through a 2-D row map) does tile 7's arithmetic in tile 7's order: outputs equal bit for bit, both at the split-bf16 bar
     against torch; shapes it does not take and a missing fragment copy are refused without writing."""
     from gen_adversarial_amd.engine_core import WeightStore
-    Cin = 32
     x = g(N, Cin, H, W, seed=1)
     w = g(Cout, Cin, 3, 3, seed=2, scale=1.0 / np.sqrt(Cin * 9))
     b = g(Cout, seed=3)
@@ -354,13 +357,16 @@ def test_conv_thin3_persistent_kernel(N, H, W, Cout, act, mode, extra):
     assert torch.isnan(y11).all(), 'a refused launch wrote its output'
     run_conv(xd, wf, y11, 3, pad=1, tile=11, w_frag=st.frag_thin(wf), **kw)
     close(nchw(y11), ref, 2e-4, 'persistent thin 3x3 kernel vs torch')
-    assert torch.equal(y7, y11), f'tile 11 differs from tile 7: max {float((y7 - y11).abs().max()):.3e}'
+    if Cin == 64 and 128 % W:          # the comparison kernel is the generic one (tile 4), which sums the two 32-channel chunks tap by tap
+        assert float((y7 - y11).abs().max()) < 1e-5
+    else:
+        assert torch.equal(y7, y11), f'tile 11 differs from tile 7: max {float((y7 - y11).abs().max()):.3e}'
 
 
 def test_conv_thin3_refuses_other_shapes():
     from gen_adversarial_amd.engine_core import WeightStore
     st = WeightStore(torch.device(DEV))
-    for (Cin, H, W) in ((64, 16, 16), (32, 12, 16), (32, 8, 24)):
+    for (Cin, H, W) in ((96, 16, 16), (32, 12, 16), (32, 8, 24), (64, 8, 24)):
         x = g(1, Cin, H, W, seed=1)
         w = g(32, Cin, 3, 3, seed=2)
         wf = fwd_w(w)

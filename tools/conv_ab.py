@@ -27,7 +27,7 @@ store = WeightStore(dev)
 hi, lo = store.split(w)
 frag = store.frag3(w)
 frag16 = store.frag3(w, m16=True)
-frag_thin = store.frag_thin(w) if Cin == 32 else None
+frag_thin = store.frag_thin(w) if Cin in (32, 64) else None
 dact = torch.randn(N, H, H, Cout, device=dev, generator=g)
 add = torch.randn(N, H, H, Cout, device=dev, generator=g)
 ys, ds = [], []

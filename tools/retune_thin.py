@@ -1,4 +1,4 @@
-"""GPU tool (round 4): tile 11 (csrc/conv_thin3.hip) is a new candidate for the 3x3 layers with 32 input channels — time those shapes
+"""GPU tool (round 4): tile 11 (csrc/conv_thin3.hip) is a new candidate for the 3x3 layers with 32 (later also 64) input channels — time those shapes
 again on every engine the bench builds (NVAE + VGG at 1024 / 512 / 256 / 32 rows, literal and shared encoder; the configs[2] and
 configs[4] defenders) and write the merged table.   python tools/retune_thin.py [out.json]"""
 import gc
@@ -17,7 +17,8 @@ dev = 'cuda:0'
 
 
 def retune(eng, what):
-    keys = {conv_key(d) for d in eng._conv_descs() if id(d) in eng._thin_ok}
+    only = int(os.environ.get('GA_RETUNE_C1', '0'))              # e.g. 64: only the shapes the 64-channel form of tile 11 takes
+    keys = {conv_key(d) for d in eng._conv_descs() if id(d) in eng._thin_ok and (not only or d.C1 == only)}
     before = {k: cache.get(k) for k in keys}
     for k in keys:
         cache.pop(k, None)
