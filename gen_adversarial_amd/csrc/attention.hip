@@ -17,12 +17,49 @@ __device__ __forceinline__ floatx4 ld4a(const float* p) { return *reinterpret_ca
 //   phase 1: thread t owns keys t, t + 256, ...: raw scores s[q][key] = scale * <q_q, k_key> for the Tq queries (queries in LDS)
 //            -> P buffer; per-query running max
 //   phase 2: block max, exp, block sum, normalise P in place
-//   phase 3: thread (q = t / 16, c = t % 16) owns out[q][8c .. 8c+7] (dh = 128) : sum over keys of P[q][key] * v[key][...]
+//   phase 3: out = P V with the keys split over thread groups (attn_weighted_rows)
 // P: [N, heads, Tq, Tk] (kept for the backward pass).
 constexpr int ATT_TQ = 16;     // style queries of GradualStyleEncoder (self.z: 1 x 16 x 512)
 
+// out[a][0 .. dh) = post * sum_key W[a][key] * M[key][0 .. dh) for the 16 queries of one (row, head) — P V of the forward pass, dS K of the
+// backward pass.  thread = (key group g, channel quad cq): 256 / (dh / 4) groups walk the keys in parallel (Tk / 8 serial steps at dh = 128;
+// round 4: one query per 16 threads walked ALL keys, 3072 dependent steps, 0.9 ms per launch); the groups' partial sums are added
+// through LDS in group order (fixed summation order).  red: 4096 floats.
+__device__ __forceinline__ void attn_weighted_rows(const float* __restrict__ W, const int Tk, const float* __restrict__ M, const int ldm,
+                                                   const int dh, float* __restrict__ out, const int ldo, const float post, float* red) {
+    const int tid = threadIdx.x, Q4 = dh >> 2, G = 256 / Q4;
+    const int g = tid / Q4, cq = tid - g * Q4;
+    floatx4 o[ATT_TQ];
+#pragma unroll
+    for (int a = 0; a < ATT_TQ; ++a) o[a] = floatx4{0.f, 0.f, 0.f, 0.f};
+    if (g < G) {
+#pragma unroll 2
+        for (int key = g; key < Tk; key += G) {
+            const floatx4 m = ld4a(M + (size_t)key * ldm + 4 * cq);
+#pragma unroll
+            for (int a = 0; a < ATT_TQ; ++a) o[a] += W[(size_t)a * Tk + key] * m;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < ATT_TQ; b += 4) {               // four queries at a time through the 16-KB buffer
+        __syncthreads();
+        if (g < G) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<floatx4*>(red + (g * 4 + j) * dh + 4 * cq) = o[b + j];
+        }
+        __syncthreads();
+        for (int t = tid; t < 4 * dh; t += 256) {
+            const int j = t / dh, c = t - j * dh;
+            float sum = 0.f;
+            for (int gg = 0; gg < G; ++gg) sum += red[(gg * 4 + j) * dh + c];
+            out[(size_t)(b + j) * ldo + c] = sum * post;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const ga_attn_desc d) {
     __shared__ float qs[ATT_TQ][132];
+    __shared__ __attribute__((aligned(16))) float wred[4096];
     __shared__ float red[ATT_TQ][256 / 64 + 1];
     __shared__ float stat[ATT_TQ];
     const int n = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
@@ -88,19 +125,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const ga_attn_desc d) {
     }
     __syncthreads();                                // P of this block is complete (same-block global writes, made visible by the barrier)
     __threadfence_block();
-    // phase 3: out[qi][c0 .. c0 + 7]
-    const int per_q = 256 / ATT_TQ;                 // 16 threads per query
-    const int qi = tid / per_q, cw = dh / per_q;    // cw = 8 channels per thread at dh = 128
-    const int c0 = (tid % per_q) * cw;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* Pq = P + (size_t)qi * Tk;
-    for (int key = 0; key < Tk; ++key) {
-        const float p = Pq[key];
-        const float* vr = v + (size_t)key * d.ldv + c0;
-        for (int c = 0; c < cw; ++c) o[c] += p * vr[c];
-    }
-    float* out = d.out + ((size_t)n * ATT_TQ + qi) * d.ldo + h * dh + c0;
-    for (int c = 0; c < cw; ++c) out[c] = o[c];
+    // phase 3: out = P V
+    attn_weighted_rows(P, Tk, v, d.ldv, dh, d.out + (size_t)n * ATT_TQ * d.ldo + h * dh, d.ldo, 1.0f, wred);
 }
 
 // attention backward.  block = (row, head).  With P the saved probabilities, dO the cotangent of the head's output:
@@ -109,6 +135,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const ga_attn_desc d) {
 // dS overwrites the `ds` scratch ([N, heads, Tq, Tk]).  dq / dk / dv are WRITTEN (each block owns its head's channel slice).
 __global__ void __launch_bounds__(256) attn_bwd_kernel(const ga_attn_desc d) {
     __shared__ float qs[ATT_TQ][132];
+    __shared__ __attribute__((aligned(16))) float wred[4096];
     __shared__ float dos[ATT_TQ][132];
     __shared__ float red[ATT_TQ][256 / 64 + 1];
     __shared__ float rdot[ATT_TQ];
@@ -176,18 +203,8 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const ga_attn_desc d) {
     }
     __syncthreads();
     __threadfence_block();
-    const int per_q = 256 / ATT_TQ;
-    const int qi = tid / per_q, cw = dh / per_q;
-    const int c0 = (tid % per_q) * cw;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* Sq = dS + (size_t)qi * Tk;
-    for (int key = 0; key < Tk; ++key) {
-        const float s = Sq[key];
-        const float* kr = k + (size_t)key * d.ldk + c0;
-        for (int c = 0; c < cw; ++c) o[c] += s * kr[c];
-    }
-    float* dq = d.dq + ((size_t)n * ATT_TQ + qi) * d.lddq + h * dh + c0;
-    for (int c = 0; c < cw; ++c) dq[c] = o[c] * d.scale;
+    // dQ = scale * dS K
+    attn_weighted_rows(dS, Tk, k, d.ldk, dh, d.dq + (size_t)n * ATT_TQ * d.lddq + h * dh, d.lddq, d.scale, wred);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
