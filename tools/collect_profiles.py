@@ -125,7 +125,7 @@ if conv:
 traffic['all_kernels_total_bytes'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for k, v in traffic.items() if k.startswith('ga::') or k == 'other')
 traffic['hot_path_kernels_total_bytes'] = sum(v['hbm_bytes_per_launch'] * v['launches'] for k, v in traffic.items() if k.startswith('ga::'))
 traffic['rows'] = CHUNK_ROWS
-traffic['hbm_bytes_per_attack_row'] = traffic['hot_path_kernels_total_bytes'] / CHUNK_ROWS.0
+traffic['hbm_bytes_per_attack_row'] = traffic['hot_path_kernels_total_bytes'] / float(CHUNK_ROWS)
 traffic['_note'] = ("'other' = PyTorch kernels of engine construction (zero-filling the activation buffers, weight upload / bf16 split): not on the "
                     "hot path; hbm_bytes_per_attack_row counts the ga:: kernels only")
 res['traffic'] = traffic
