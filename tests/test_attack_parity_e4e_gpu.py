@@ -1,0 +1,94 @@
+"""
+GPU: the reference's attacks on the e4e + StyleGAN2 defender of the gender experiment (SURVEY.md §8 rows a14 - a17, a19:
+E4EStyleGanDefenseModel behind load(args) and EoTWrapper, src/defenses/ours/models.py:80-132, src/defenses/wrappers.py:15-24)
+against the same attacks on the CPU oracle of that defender (oracle.defender_oracle.e4e_defender_call) with the mapped noise pinned.
+Same two comparisons as tests/test_attack_parity_gpu.py (whose helpers are used): every query of the oracle run replayed on the HIP
+defender (logits 1e-3, input gradients on every element given the engine's PReLU / LeakyReLU / ReLU / max-pool decisions) and the
+free-running `(success, L2, adversarial image)`.  Reduced configuration (quarter-width IR-SE encoder, 1/8-width 64-px generator,
+1/8-width ResNet: tests/test_host_cpu._small_e4e_defense); DeepFool takes its two class gradients from `class_jacobian`, which on
+this defender replays the backward plan once per class on the retained forward.
+"""
+from argparse import Namespace
+
+import pytest
+import torch
+import yaml
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():
+    pytest.skip('needs a GPU', allow_module_level=True)
+
+from test_attack_parity_gpu import EOT, _both   # noqa: E402
+from test_host_cpu import _small_e4e_defense   # noqa: E402
+
+from gen_adversarial_amd.attacks.l2_attacks import APGDAttack, DeepFool   # noqa: E402
+from gen_adversarial_amd.experiments.load_defense import load   # noqa: E402
+from oracle import defender_oracle as D   # noqa: E402
+
+DEV = 'cuda:0'
+MAXB = 2
+
+
+class E4EEoTOracle(torch.nn.Module):
+    """EoTWrapper(E4EStyleGanDefenseModel(classifier)) as one differentiable CPU callable, draws pinned: image b becomes rows
+    b*eot .. b*eot+eot-1, row r of a call mixes in mapping(z[r])"""
+
+    def __init__(self, parts, eot, z, pool_to):
+        super().__init__()
+        self.parts, self.eot, self.z, self.pool_to = parts, eot, z, pool_to
+
+    def forward(self, x):
+        esd, espec, gsd, gspec, avg, csd, cspec, alphas = self.parts
+        B = x.shape[0]
+        xr = x.repeat_interleave(self.eot, dim=0)
+        # MLVGMDefenseModel.__call__ always goes through add_gaussian_noise (abstract_models.py:176-177): with eps = 0 that is the
+        # clamp to [0, 1] alone — DeepFool's iterates leave the box, e4e_defender_call expects the clamped batch
+        xr = D.add_gaussian_noise(xr, torch.ones_like(xr), 0.0)
+        lg, _ = D.e4e_defender_call(esd, espec, gsd, gspec, avg, csd, cspec, xr, alphas, self.z[:B * self.eot], self.pool_to)
+        return lg.view(B, self.eot, -1).mean(dim=1)
+
+
+@pytest.fixture(scope='module')
+def pair(tmp_path_factory):
+    d = tmp_path_factory.mktemp('ckpt_e4e')
+    _, parts = _small_e4e_defense(dry_run=True, device='cpu')
+    esd, espec, gsd, gspec, avg, csd, cspec, alphas = parts
+    ck = {'state_dict': {**{'encoder.' + k: v for k, v in esd.items()}, **{'decoder.' + k: v for k, v in gsd.items()}},
+          'latent_avg': avg, 'opts': {'stylegan_size': gspec.size, 'start_from_latent_avg': True, 'encoder_type': 'Encoder4Editing'}}
+    torch.save(ck, d / 'e4e.pt')
+    torch.save({'state_dict': csd}, d / 'resnet.pt')
+    with open(d / 'cfg.yaml', 'w') as f:
+        yaml.safe_dump({'classifier_path': str(d / 'resnet.pt'), 'autoencoder_path': str(d / 'e4e.pt'),
+                        'interpolation_alphas': [a / 0.5 for a in alphas], 'alpha_attenuation': 0.5, 'initial_noise_eps': 0.0,
+                        'gaussian_blur_input': False}, f)
+    args, model = load(Namespace(config=str(d / 'cfg.yaml'), experiment='gender', defense_type='ours', eot_steps=EOT, device=DEV))
+    z = torch.randn(MAXB * EOT, gspec.n_latent, gspec.style_dim, generator=torch.Generator().manual_seed(21))
+    oracle = E4EEoTOracle(parts, EOT, z, 64)
+    model.model.fixed_noise([z.to(DEV)], None)
+    yield model, oracle
+    model.model.fixed_noise(None, None)
+
+
+def _images(n, seed):
+    return torch.rand(n, 3, 64, 64, generator=torch.Generator().manual_seed(seed))
+
+
+def test_apgd_ce_on_the_e4e_defender_equals_oracle(pair):
+    model, oracle = pair
+    x = _images(2, 400)
+    with torch.no_grad():
+        labels = oracle(x).argmax(dim=1)
+    init = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(6))
+    bound = 2.0
+    res_hip, _ = _both('e4e APGD-CE', lambda: APGDAttack(n_iter=6, rho=0.75, max_bound=bound, ce_loss=True), x, labels, model, oracle,
+                       init_noise=init)
+    assert float(torch.as_tensor(res_hip[1]).max()) <= bound + 1e-3
+
+
+def test_deepfool_on_the_e4e_defender_equals_oracle(pair):
+    model, oracle = pair
+    x = _images(1, 401)
+    with torch.no_grad():
+        labels = oracle(x).argmax(dim=1)
+    _both('e4e DeepFool', lambda: DeepFool(num_classes=2, overshoot=0.02, max_iter=8), x, labels, model, oracle)
