@@ -25,7 +25,7 @@ GA_CONV_ADDEND_RELU, GA_CONV_ADDEND_PRE_DACT, GA_CONV_PRO_PRELU, GA_CONV_DACT_PR
  GA_OP_MAXPOOL3S2, GA_OP_AVGPOOL_ACT, GA_OP_GCONV, GA_OP_PRELU, GA_OP_UNARY, GA_OP_MODOUT, GA_OP_UP2_BLUR, GA_OP_PIXELNORM,
  GA_OP_LATENT_MIX, GA_OP_POOL_DENORM, GA_OP_ATTN, GA_OP_LAYERNORM, GA_OP_RESIZE2_CROP, GA_OP_DEC_CELL, GA_OP_AVAE, GA_OP_DEC_CELL_HALO) = range(1, 31)
 GA_AVAE_ADAIN, GA_AVAE_AVGPOOL, GA_AVAE_PIXELNORM, GA_AVAE_SAMPLE = 0, 1, 2, 3
-ABI_VERSION = 6     # include/ga_ops.h: GA_ABI_VERSION (descriptor layouts + entry points); _load() refuses any other library
+ABI_VERSION = 7     # include/ga_ops.h: GA_ABI_VERSION (descriptor layouts + entry points); _load() refuses any other library
 ERRORS = {0: 'GA_OK', -1: 'GA_E_BADARG', -2: 'GA_E_ALIGN', -3: 'GA_E_UNSUPPORTED', -4: 'GA_E_LAUNCH'}
 
 fp = C.c_void_p     # device pointers travel as integers
@@ -55,7 +55,7 @@ class DwDesc(C.Structure):
 
 class ReduceDesc(C.Structure):
     _fields_ = [('a', fp), ('b', fp), ('out', fp), ('N', i32), ('P', i32), ('C', i32), ('scale', f32),
-                ('ws', fp), ('ws_floats', C.c_long), ('gate', fp), ('skip', fp), ('scaled', fp)]
+                ('ws', fp), ('ws_floats', C.c_long), ('gate', fp), ('skip', fp), ('scaled', fp), ('a_src', fp), ('a_w', fp)]
 
 
 class SeExciteDesc(C.Structure):

@@ -4,6 +4,29 @@
 
 namespace ga {
 
+// operand a of the reduce pass at (n, p, c .. c+3): stored, or formed from a 4-lane tensor by a 1x1 transposed conv (a_src, a_w)
+struct reduce_a_src {
+    const float* a; const float* src; floatx4 w0, w1, w2, w3; int C;
+    __device__ __forceinline__ reduce_a_src(const ga_rowchan_reduce_desc& d, const int n, const int c) : C(d.C) {
+        a = d.a ? d.a + (size_t)n * d.P * d.C + c : nullptr;
+        src = d.a ? nullptr : d.a_src + (size_t)n * d.P * 4;
+        if (!d.a) {
+            w0 = *reinterpret_cast<const floatx4*>(d.a_w + (size_t)(c + 0) * 4); w1 = *reinterpret_cast<const floatx4*>(d.a_w + (size_t)(c + 1) * 4);
+            w2 = *reinterpret_cast<const floatx4*>(d.a_w + (size_t)(c + 2) * 4); w3 = *reinterpret_cast<const floatx4*>(d.a_w + (size_t)(c + 3) * 4);
+        }
+    }
+    __device__ __forceinline__ floatx4 operator()(const int p) const {
+        if (a) return *reinterpret_cast<const floatx4*>(a + (size_t)p * C);
+        const floatx4 s = *reinterpret_cast<const floatx4*>(src + (size_t)p * 4);
+        floatx4 v;
+        v[0] = w0[0] * s[0] + w0[1] * s[1] + w0[2] * s[2] + w0[3] * s[3];
+        v[1] = w1[0] * s[0] + w1[1] * s[1] + w1[2] * s[2] + w1[3] * s[3];
+        v[2] = w2[0] * s[0] + w2[1] * s[1] + w2[2] * s[2] + w2[3] * s[3];
+        v[3] = w3[0] * s[0] + w3[1] * s[1] + w3[2] * s[2] + w3[3] * s[3];
+        return v;
+    }
+};
+
 // optional second output of the reduce pass: scaled = a * gate[n,c] (+ skip) with ga_se_apply's rounding (one fma per element)
 __device__ __forceinline__ void reduce_scaled_store(const ga_rowchan_reduce_desc& d, const floatx4 gt, const size_t o, const floatx4 a) {
     floatx4 sk = {0.f, 0.f, 0.f, 0.f}, r;
@@ -25,13 +48,13 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
     const int c = chunk * 64 + 4 * c4;
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c < d.C) {
-        const float* a = d.a + (size_t)n * d.P * d.C + c;
+        const reduce_a_src a(d, n, c);
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
         if (d.scaled) {
             const floatx4 gt = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
 #pragma unroll 4
             for (int p = pl; p < d.P; p += 16) {
-                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                floatx4 v = a(p);
                 reduce_scaled_store(d, gt, ((size_t)n * d.P + p) * d.C + c, v);
                 if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
                 acc += v;
@@ -39,7 +62,7 @@ __global__ void __launch_bounds__(256) rowchan_reduce_kernel(const ga_rowchan_re
         } else {
 #pragma unroll 8
             for (int p = pl; p < d.P; p += 16) {
-                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                floatx4 v = a(p);
                 if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
                 acc += v;
             }
@@ -67,14 +90,14 @@ __global__ void __launch_bounds__(256) rowchan_reduce_split_kernel(const ga_rowc
     const int c = chunk * 64 + 4 * c4;
     floatx4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c < d.C) {
-        const float* a = d.a + (size_t)n * d.P * d.C + c;
+        const reduce_a_src a(d, n, c);
         const float* b = d.b ? d.b + (size_t)n * d.P * d.C + c : nullptr;
         const int p1 = min(d.P, (seg + 1) * seg_len);
         if (d.scaled) {
             const floatx4 gt = *reinterpret_cast<const floatx4*>(d.gate + (size_t)n * d.C + c);
 #pragma unroll 4
             for (int p = seg * seg_len + pl; p < p1; p += PL) {
-                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                floatx4 v = a(p);
                 reduce_scaled_store(d, gt, ((size_t)n * d.P + p) * d.C + c, v);
                 if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
                 acc += v;
@@ -82,7 +105,7 @@ __global__ void __launch_bounds__(256) rowchan_reduce_split_kernel(const ga_rowc
         } else {
 #pragma unroll 8
             for (int p = seg * seg_len + pl; p < p1; p += PL) {
-                floatx4 v = *reinterpret_cast<const floatx4*>(a + (size_t)p * d.C);
+                floatx4 v = a(p);
                 if (b) v *= *reinterpret_cast<const floatx4*>(b + (size_t)p * d.C);
                 acc += v;
             }
@@ -1205,9 +1228,10 @@ using namespace ga;
 
 extern "C" int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* s) {
     ga::clear_stale_error();
-    if (!d || !d->a || !d->out || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
+    if (!d || (!d->a && !(d->a_src && d->a_w)) || !d->out || d->N <= 0 || d->P <= 0 || d->C <= 0) return GA_E_BADARG;
     if (d->C % 4) return GA_E_UNSUPPORTED;
-    if (!aligned16(d->a) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
+    if ((d->a && !aligned16(d->a)) || !aligned16(d->out) || (d->b && !aligned16(d->b))) return GA_E_ALIGN;
+    if (!d->a && (!aligned16(d->a_src) || !aligned16(d->a_w))) return GA_E_ALIGN;
     if (d->scaled && (!d->gate || !aligned16(d->scaled) || !aligned16(d->gate) || (d->skip && !aligned16(d->skip)))) return GA_E_BADARG;
     const int nchunks = (d->C + 63) / 64;
     if (d->ws && d->P >= 4096 && d->N * nchunks < 1024) {

@@ -137,14 +137,18 @@ class StyleGanBuilder:
                 b.red, b.ws, b.ws_floats = _ptr(gq), _ptr(ws), ws.numel()
             self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
-            dxm = self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
+            # ToRGB (1x1, 3 -> 4 output lanes): d(x*s) = W^T dt is formed inside the reduction pass from the 4-lane cotangent — the
+            # Cin-wide tensor (4.3 GB at 1024 x 1024 x 32 channels x 32 rows) is neither written nor read (ga_rowchan_reduce a_src / a_w)
+            torgb = k == 1 and not spec.upsample and co == 4 and tuple(wts['w_bwd'].shape) == (spec.cin, 4)
+            dxm = None if torgb else self.scratch((R, rin, rin, spec.cin), 'sg.dxm')
             if spec.upsample:                                    # adjoint of (transposed conv + blur): one 3x3 conv 4*Cout -> Cin
                 self.conv(self.bwd, f'{p}.conv^T[parities]', s2d_g, wts['up_all_bwd'], dxm, K=3, pad=1)
-            else:
+            elif not torgb:
                 self.conv(self.bwd, f'{p}.conv^T', t.g, wts['w_bwd'], dxm, K=k, pad=k // 2)
             # sum_p dxm * x (style gradient) and d x = dxm * s (+ an already written x.g) from ONE read of dxm (round 4)
-            self._reduce(f'{p}.dstyle_conv' + ('+dx' if need_dx else ''), dxm, x.t, ds, R, Pin, spec.cin,
-                         scaled=(x.g if need_dx else None), gate=s.t, skip=(x.g if need_dx and x.g_written else None))
+            self._reduce(f'{p}.' + ('conv^T+' if torgb else '') + 'dstyle_conv' + ('+dx' if need_dx else ''), dxm, x.t, ds, R, Pin, spec.cin,
+                         scaled=(x.g if need_dx else None), gate=s.t, skip=(x.g if need_dx and x.g_written else None),
+                         a_src=(t.g if torgb else None), a_w=(wts['w_bwd'] if torgb else None))
             if need_dx:
                 x.g_written = True
             if spec.demodulate:
@@ -276,9 +280,11 @@ class StyleGanBuilder:
         u.x, u.g, u.y, u.n, u.mode, u.eps = _ptr(x), _ptr(g), _ptr(y), y.numel(), mode, eps
         plan.add(u, name)
 
-    def _reduce(self, name, a, b, out, n, p, c, scaled=None, gate=None, skip=None):
+    def _reduce(self, name, a, b, out, n, p, c, scaled=None, gate=None, skip=None, a_src=None, a_w=None):
         r = L.ReduceDesc()
         r.a, r.b, r.out, r.N, r.P, r.C, r.scale = _ptr(a), _ptr(b), _ptr(out), n, p, c, 1.0
+        if a is None:
+            r.a_src, r.a_w = _ptr(a_src), _ptr(a_w)
         if scaled is not None:
             r.scaled, r.gate, r.skip = _ptr(scaled), _ptr(gate), _ptr(skip)
         if p >= 4096:                                    # long rows: split the pixels over workgroups (two-stage reduction)

@@ -147,6 +147,10 @@ typedef struct ga_rowchan_reduce_desc {
      *   scaled[n,p,c] = a[n,p,c] * gate[n,c] (+ skip[n,p,c])     — d x = d(x*s) * s beside the style gradient sum_p d(x*s) * x,
      * one read of `a` for both.  skip may alias scaled (accumulating into an already written gradient). */
     const float* gate; const float* skip; float* scaled;
+    /* a == NULL: `a` is formed on the fly as a 1x1 transposed conv of a 4-lane tensor — a[n,p,c] = sum_{k<4} a_w[c][k] * a_src[n,p,k]
+     * (a_src [N,P,4], a_w [C][4]: ToRGB's backward, generator.py:268-290 differentiated: the 32 .. 512-channel d(x*s) of a 3-channel
+     * cotangent is never stored; exact fp32 products) */
+    const float* a_src; const float* a_w;
 } ga_rowchan_reduce_desc;
 int ga_rowchan_reduce(const ga_rowchan_reduce_desc* d, void* stream);
 
@@ -606,7 +610,7 @@ long ga_debug_set_conv_row_limit(long bytes);
 const char* ga_last_hip_error(void);
 /* GA_ABI_VERSION is bumped with EVERY change of a descriptor's layout or meaning (a field added, a reserved field put to use) and
  * with every entry point added; the binding (gen_adversarial_amd/_lib.py: ABI_VERSION) refuses a library that reports another one. */
-#define GA_ABI_VERSION 6
+#define GA_ABI_VERSION 7
 int ga_abi_version(void);
 unsigned long ga_sizeof_op(void);
 

@@ -1117,6 +1117,40 @@ def test_rowchan_reduce_with_scaled_output(N, P, C, two_stage, with_skip):
     assert L.lib.ga_rowchan_reduce(ctypes.byref(d), st) == -1           # GA_E_BADARG
 
 
+@pytest.mark.parametrize('N,P,C,two_stage', [(2, 9000, 32, True), (3, 500, 64, False), (1, 65536, 32, True), (2, 4096, 512, True)])
+def test_rowchan_reduce_forms_its_operand_from_a_4_lane_tensor(N, P, C, two_stage):
+    """ToRGB backward: a[n,p,c] = sum_k a_w[c][k] a_src[n,p,k] is never stored; sum_p a * b and scaled = a * gate + skip equal the pass
+    over a materialised `a` (same kernel, stored operand) to rounding of the 4-term dot product"""
+    gen = torch.Generator().manual_seed(N * 100 + C)
+    src = torch.randn(N, P, 4, generator=gen).to(DEV)
+    src[..., 3] = 0.0                                                  # the padded lane of a 3-channel image
+    w = (torch.randn(C, 4, generator=gen) * 0.5).to(DEV)
+    b, gate, acc0 = torch.randn(N, P, C, generator=gen).to(DEV), torch.randn(N, C, generator=gen).to(DEV), torch.randn(N, P, C, generator=gen).to(DEV)
+    a = torch.einsum('npk,ck->npc', src.double(), w.double())
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.zeros(64 * N * C, device=DEV)
+    out, scaled = torch.zeros(N, C, device=DEV), acc0.clone()
+    d = L.ReduceDesc()
+    d.a_src, d.a_w, d.b, d.out, d.N, d.P, d.C, d.scale = src.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), N, P, C, 1.0
+    d.gate, d.skip, d.scaled = gate.data_ptr(), scaled.data_ptr(), scaled.data_ptr()
+    if two_stage:
+        d.ws, d.ws_floats = ws.data_ptr(), ws.numel()
+    L.run(d, st)
+    torch.cuda.synchronize()
+    ref = (a * b.double()).sum(dim=1)
+    assert (out.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    want = a * gate.double()[:, None, :] + acc0.double()
+    assert (scaled.double() - want).abs().max().item() < 1e-5
+    first = out.clone()
+    scaled.copy_(acc0)
+    L.run(d, st)
+    torch.cuda.synchronize()
+    assert torch.equal(first, out)                                     # deterministic
+    d.a_w = None
+    import ctypes
+    assert L.lib.ga_rowchan_reduce(ctypes.byref(d), st) == -1          # neither a nor (a_src, a_w)
+
+
 @pytest.mark.parametrize('N,H,C,with_red,act', [(2, 16, 32, True, L.GA_ACT_FLRELU), (3, 8, 8, False, L.GA_ACT_FLRELU), (1, 64, 64, True, L.GA_ACT_NONE)])
 def test_modout_reads_t_in_depth_to_space_form(N, H, C, with_red, act):
     """the up-sampling StyledConv keeps t in the parity conv's depth-to-space form: tail forward, its adjoint (dt in planes only) and the
