@@ -76,7 +76,14 @@ class StyleGanBuilder:
         zeros = self.devd(f'sg.zeros.{R}.{spec.cin}', lambda: {'z': torch.zeros(R, spec.cin)})['z']
         pro = dict(pro_scale=s.t, pro_shift=zeros, pro_per_row=1)
         t = s2d = None
-        if spec.upsample:                # all four parities as one 3x3 conv Cin -> 4*Cout over the low-resolution input; t STAYS in
+        # ToRGB (no demodulation, no activation, no noise): the tail is `+ bias` — the conv's own bias; no tail pass in either direction,
+        # the cotangent of t IS the cotangent of out
+        plain = (not spec.demodulate) and (not spec.activate) and noise is None and not spec.upsample
+        out = Act(self, R, spec.res, spec.res, co, f'{p}.out')
+        if plain:
+            t = out
+            self.conv(self.fwd, f'{p}.conv', x.t, wts['w'], out.t, bias=wts['add'][0], K=k, pad=k // 2, **pro)
+        elif spec.upsample:                # all four parities as one 3x3 conv Cin -> 4*Cout over the low-resolution input; t STAYS in
             # that depth-to-space form [R, rin, rin, 4*Cout] (channel block i = parity plane i): the tail and its adjoint read it through
             # ga_modout_desc.t_planes — no interleave pass, no interleaved copy of t or of its gradient (round 4)
             s2d = self.alloc((R, rin, rin, 4 * co))
@@ -100,12 +107,12 @@ class StyleGanBuilder:
             self._unary(self.fwd, f'{p}.style^2', 0, s.t, None, s2)
             self.conv(self.fwd, f'{p}.demod_sum', s2, wts['w2'], q, K=1)
             self._unary(self.fwd, f'{p}.demod', 2, q, None, demod, eps=1e-8)
-        out = Act(self, R, spec.res, spec.res, co, f'{p}.out')
-        m = L.ModoutDesc()
-        m.scale, m.add, m.out = _ptr(demod), _ptr(wts['add']), _ptr(out.t)
-        m.N, m.P, m.C, m.act, m.backward = R, P, co, act, 0
-        tail_t(m)
-        self.fwd.add(m, f'{p}.tail')
+        if not plain:
+            m = L.ModoutDesc()
+            m.scale, m.add, m.out = _ptr(demod), _ptr(wts['add']), _ptr(out.t)
+            m.N, m.P, m.C, m.act, m.backward = R, P, co, act, 0
+            tail_t(m)
+            self.fwd.add(m, f'{p}.tail')
         if skip is not None:
             assert (skip.n, skip.h, skip.w, skip.c) == (R, spec.res // 2, spec.res // 2, co), p
             u = L.Up2BlurDesc()
@@ -122,9 +129,12 @@ class StyleGanBuilder:
             b = L.ModoutDesc()
             b.scale, b.add, b.dout = _ptr(demod), _ptr(wts['add']), _ptr(out.g)
             b.N, b.P, b.C, b.act, b.backward = R, P, co, act, 1
-            tail_t(b)
+            if not plain:
+                tail_t(b)
             s2d_g = None
-            if spec.upsample:                                    # dt in depth-to-space form only: the operand of the parity adjoint
+            if plain:
+                pass
+            elif spec.upsample:                                    # dt in depth-to-space form only: the operand of the parity adjoint
                 s2d_g = self.scratch((R, rin, rin, 4 * co), 'sg.up_s2d_g')
                 for i in range(4):
                     b.dt_planes[i] = _ptr(s2d_g) + 4 * i * co
@@ -135,7 +145,8 @@ class StyleGanBuilder:
                 gq = self.scratch((R, 1, 1, co), 'sg.gq')
                 ws = self.scratch((256 * R * co,), 'sg.tail_ws')
                 b.red, b.ws, b.ws_floats = _ptr(gq), _ptr(ws), ws.numel()
-            self.bwd.add(b, f'{p}.tail^T')
+            if not plain:
+                self.bwd.add(b, f'{p}.tail^T')
             ds = self.scratch((R, 1, 1, spec.cin), 'sg.ds')
             # ToRGB (1x1, 3 -> 4 output lanes): d(x*s) = W^T dt is formed inside the reduction pass from the 4-lane cotangent — the
             # Cin-wide tensor (4.3 GB at 1024 x 1024 x 32 channels x 32 rows) is neither written nor read (ga_rowchan_reduce a_src / a_w)
