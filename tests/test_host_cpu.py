@@ -474,3 +474,23 @@ def test_competitor_defender_plans_build_without_a_gpu():
             assert sum(isinstance(d, L.AvaeDesc) and d.mode == L.GA_AVAE_ADAIN for d in eng.fwd.descs) == 2 * len(aspec.blocks)
             assert b.index('avae.to_rgb^T') >= eng.bwd_split > 0 and b.index('avae.sample^T') > b.index('generator.progression.0.adain1^T')
             assert len(eng.eps) == 1 + len(aspec.blocks)
+
+
+@pytest.mark.parametrize('cin,cout', [(32, 32), (32, 104), (64, 64), (64, 8)])
+def test_thin_kernel_weight_fragments_follow_the_header(cin, cout):
+    """include/ga_ops.h, ga_conv_desc.w_frag, tile 11: bf16 [ceil(Cout/32)][9 taps][C1/16 k steps][hi | lo][64 lanes][8] with element e
+    of lane l = W[32 t + (l & 31)][tap * C1 + 16 kstep + 8 (l >> 5) + e], rows >= Cout zero, hi + lo the bf16 split of W"""
+    w = torch.randn(cout, 9 * cin, generator=torch.Generator().manual_seed(cin + cout))
+    store = WeightStore('cpu')
+    f = store.frag_thin(w)
+    nt, ks = (cout + 31) // 32, cin // 16
+    assert f.dtype == torch.bfloat16 and tuple(f.shape) == (nt, 9, ks, 2, 2, 32, 8)        # [.., hi | lo, lane >> 5, lane & 31, e]
+    hi, lo = store.split(w)
+    gen = torch.Generator().manual_seed(1)
+    for _ in range(200):
+        t, tap, k, part = (int(torch.randint(n, (1,), generator=gen)) for n in (nt, 9, ks, 2))
+        lane, e = int(torch.randint(64, (1,), generator=gen)), int(torch.randint(8, (1,), generator=gen))
+        row, col = 32 * t + (lane & 31), tap * cin + 16 * k + 8 * (lane >> 5) + e
+        want = (hi, lo)[part][row, col] if row < cout else torch.zeros((), dtype=torch.bfloat16)
+        assert f[t, tap, k, part, lane >> 5, lane & 31, e] == want, (t, tap, k, part, lane, e)
+    assert torch.equal(hi.float() + lo.float(), (w.to(torch.bfloat16).float() + (w - w.to(torch.bfloat16).float()).to(torch.bfloat16).float()))
