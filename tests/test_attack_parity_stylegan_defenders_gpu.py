@@ -93,7 +93,7 @@ def test_deepfool_on_the_e4e_defender_equals_oracle(pair):
     x = _images(1, 401)
     with torch.no_grad():
         labels = oracle(x).argmax(dim=1)
-    _both('e4e DeepFool', lambda: DeepFool(num_classes=2, overshoot=0.02, max_iter=8), x, labels, model, oracle)
+    _both('e4e DeepFool', lambda: DeepFool(num_classes=2, overshoot=0.02, max_iter=3), x, labels, model, oracle)
 
 
 # ------------------------------------------------------------------------------------------------ Style-Transformer defender (cars)
