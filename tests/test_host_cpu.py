@@ -494,3 +494,34 @@ def test_thin_kernel_weight_fragments_follow_the_header(cin, cout):
         want = (hi, lo)[part][row, col] if row < cout else torch.zeros((), dtype=torch.bfloat16)
         assert f[t, tap, k, part, lane >> 5, lane & 31, e] == want, (t, tap, k, part, lane, e)
     assert torch.equal(hi.float() + lo.float(), (w.to(torch.bfloat16).float() + (w - w.to(torch.bfloat16).float()).to(torch.bfloat16).float()))
+
+
+def test_torgb_layers_have_no_tail_pass_and_no_backward_conv():
+    """round 4 (engine_stylegan.py): ToRGB's tail is its conv's bias, its backward conv W^T dt is formed inside the style-gradient /
+    dx reduction (ga_rowchan_reduce a_src / a_w); the up-sampling layers keep t in depth-to-space form (t_planes, no interleave)"""
+    from gen_adversarial_amd.engine_core import Act
+    from gen_adversarial_amd.stylegan_spec import build_stylegan_spec, init_stylegan_state_dict
+    spec = build_stylegan_spec(32, width_div=16, style_dim=64)
+    eng = Engine.bare(2, device='cpu', dry_run=True)
+    lat = Act(eng, 2, 1, 1, spec.n_latent * spec.style_dim, 'latent')
+    eng.build_stylegan(init_stylegan_state_dict(spec, 3), spec, lat)
+    eng.finish()
+    fwd, bwd = dict(zip(eng.fwd.names, eng.fwd.descs)), dict(zip(eng.bwd.names, eng.bwd.descs))
+    assert not any(n.startswith('to_rgb') and n.endswith('.tail') for n in fwd) and 'convs.0.tail' in fwd
+    assert not any(n.startswith('to_rgb') and (n.endswith('.tail^T') or n.endswith('.conv^T')) for n in bwd)
+    r = bwd['to_rgbs.0.conv^T+dstyle_conv+dx']
+    assert isinstance(r, L.ReduceDesc) and not r.a and r.a_src and r.a_w and r.scaled and r.gate
+    up = fwd['convs.0.tail']                                    # convs.0 up-samples: its tail reads the parity conv's planes
+    assert not up.t and all(up.t_planes[i] for i in range(4)) and up.ld_planes == 4 * up.C
+    upb = bwd['convs.0.tail^T']
+    assert not upb.dt and all(upb.dt_planes[i] for i in range(4))
+    plain = fwd['convs.1.tail']                                 # convs.1 does not: interleaved t, interleaved dt
+    assert plain.t and not plain.t_planes[0] and bwd['convs.1.tail^T'].dt
+
+
+def test_se_squeeze_of_few_large_rows_is_reduced_over_the_chip():
+    """Engine._se_wide_rows: the IR-SE50 rows of the e4e / Style-Transformer defenders (32 - 64 rows of >= 1 MB) go through
+    ga_rowchan_reduce; the NVAE cells (hundreds of small rows, or 32 rows of <= 0.5 MB) keep the fused one-workgroup-per-row squeeze"""
+    assert Engine._se_wide_rows(32, 128 * 128, 64) and Engine._se_wide_rows(64, 32 * 32, 256)
+    assert not Engine._se_wide_rows(1024, 128 * 128, 64)        # many rows: the fused form fills the chip
+    assert not Engine._se_wide_rows(32, 64 * 64, 32) and not Engine._se_wide_rows(32, 16 * 16, 128)      # NVAE at 32 rows
